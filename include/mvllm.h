@@ -1,0 +1,161 @@
+/*
+ * mvllm.h - C ABI of the MI355X (gfx950) paged-KV decode path.
+ *
+ * Every entry point is a plain C function: raw device pointers, sizes and
+ * strides in ELEMENTS, an explicit hipStream_t (passed as void*), and an int
+ * return code (0 = ok, negative = mv_status below).  Nothing here allocates,
+ * frees or synchronises: the caller owns every buffer, and all launches are
+ * legal under HIP stream capture.  All tensors are bf16 unless a parameter
+ * says otherwise; accumulation is fp32.
+ *
+ * Each declaration names the reference call it stands in for
+ * (paths relative to the micro-vllm checkout).
+ */
+#ifndef MVLLM_H
+#define MVLLM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mv_stream_t; /* hipStream_t */
+
+enum mv_status {
+    MV_OK = 0,
+    MV_ERR_INVALID_ARG = -1, /* null pointer, non-positive size, misalignment */
+    MV_ERR_UNSUPPORTED = -2, /* shape outside what the kernels are built for  */
+    MV_ERR_LAUNCH = -3,      /* hipGetLastError() after the launch was not ok */
+    MV_ERR_WORKSPACE = -4,   /* caller workspace too small                    */
+    MV_ERR_GRAPH = -5        /* stream-capture / graph API failure            */
+};
+
+/* Library identity and error text. */
+int mv_version(void);
+const char* mv_status_string(int status);
+/* Last HIP error string seen by this thread's most recent failing call. */
+const char* mv_last_hip_error(void);
+
+/* ------------------------------------------------------------------ norms */
+
+/* y[r,:] = bf16( (x[r,:] * rsqrt(mean(x[r,:]^2) + eps)) * w ), fp32 math.
+ * Replaces kernel/rmsnorm_add.py:170 rmsnorm_ (decode, writes a static
+ * buffer) and kernel/rmsnorm_add.py:37 rmsnorm (prefill). */
+int mv_rmsnorm(const void* x, const void* w, void* y, int rows, int n,
+               int64_t stride_x, int64_t stride_y, float eps, mv_stream_t stream);
+
+/* s = x + r (fp32); res_out = bf16(s); var from the UNROUNDED s;
+ * y = bf16( (float(res_out) * rrms) * w ).
+ * Replaces kernel/rmsnorm_residual.py:127 rmsnorm_residual_gemm and
+ * kernel/rmsnorm_add.py:89 rmsnorm_residual_fused. */
+int mv_rmsnorm_residual(const void* x, const void* r, const void* w, void* y, void* res_out,
+                        int rows, int n, int64_t stride_x, int64_t stride_r, int64_t stride_y,
+                        int64_t stride_res, float eps, mv_stream_t stream);
+
+/* out[r,c] = bf16( gate*sigmoid(gate)*up ), up = gate_up[r,c], gate = gate_up[r,c+d].
+ * Replaces kernel/swiglu.py:100 swiglu_gemm and :49 swiglu_fused. */
+int mv_swiglu(const void* gate_up, void* out, int64_t rows, int d, mv_stream_t stream);
+
+/* out = bf16(float(a) + float(b)), n elements (in place allowed: out == a).
+ * Replaces the `.add_(self._residual[:bs])` of core/layer/model_graph.py:219
+ * and the bias add of :147 (broadcast form: b has `n_b` elements, n % n_b == 0). */
+int mv_add(const void* a, const void* b, void* out, int64_t n, int64_t n_b, mv_stream_t stream);
+
+/* out[r,:] = table[ids[r],:].  Replaces model.transformer.wte(input_ids),
+ * core/layer/model_graph.py:196.  ids are int64 (torch.long). */
+int mv_embedding(const void* table, const int64_t* ids, void* out, int rows, int n,
+                 int64_t vocab, mv_stream_t stream);
+
+/* ------------------------------------------------- weight-streaming GEMM */
+
+/* One-time relayout of a [N,K] row-major bf16 weight (torch Linear.weight,
+ * y = x @ W^T) into wave tiles: tile (nt,kt) holds rows 16nt..16nt+15 and
+ * columns 32kt..32kt+31 as 1 KiB, lane l owning W[16nt + (l&15)][32kt + 8(l>>4) + 0..7].
+ * N % 16 == 0, K % 32 == 0.  Replaces the `.t().contiguous()` relayout of
+ * core/layer/model_graph.py:87-118 prepare_weights. */
+int mv_shuffle_weight(const void* w_nk, void* w_tiles, int n, int k, mv_stream_t stream);
+
+/* Rows of `a` and `b` interleaved in groups of 8: out rows [16j,16j+8) = a rows
+ * [8j,8j+8), out rows [16j+8,16j+16) = b rows [8j,8j+8).  Used to put `up`
+ * and `gate` rows of one output column into the same wave tile. */
+int mv_interleave_rows8(const void* a, const void* b, void* out, int rows_each, int k,
+                        mv_stream_t stream);
+
+/* Bytes of workspace mv_wgemm needs for the given problem (0 if none). */
+size_t mv_wgemm_workspace_bytes(int m, int n, int k);
+
+/* y[m, :] = bf16( bf16( bf16(x[m,:] @ W^T) + bias ) + residual[m,:] ), the two
+ * optional terms each adding one bf16 rounding exactly where the reference's
+ * `torch.matmul(out=)`, `.add_(bias)` and `.add_(residual)` round.
+ * x: [M,K] (row stride ldx), W: tiles from mv_shuffle_weight, y: [M,N].
+ * 1 <= M <= 64.  flags: MV_GEMM_* below.
+ * Replaces the decode projections torch.matmul(..., out=) at
+ * core/layer/model_graph.py:145,171,183,185 and model.lm_head (:223). */
+enum {
+    MV_GEMM_DEFAULT = 0,
+    MV_GEMM_SWIGLU = 1, /* W rows are up/gate interleaved by 8 (mv_interleave_rows8);
+                           y is [M, N/2] = swiglu(bf16(x @ W^T)), i.e. the matmul
+                           + swiglu_gemm pair of model_graph.py:183-184 in one pass */
+    MV_GEMM_OUT_F32 = 2 /* y is fp32 [M,N]: the un-rounded accumulators (tests) */
+};
+int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
+             const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n, int k,
+             void* workspace, size_t workspace_bytes, int flags, mv_stream_t stream);
+
+/* Launch-shape knobs for experiments (no counterpart in the reference):
+ * key 0 = workgroups per CU the grid is sized for (1..8, default 2);
+ * key 1 = forced number of k-slices per strip (0 = pick automatically). */
+int mv_wgemm_tune(int key, int value);
+
+/* ---------------------------------------------------- paged attention */
+
+/* Bytes of fp32 workspace for split-KV partial results. */
+size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_splits);
+
+/* How many KV splits the library would pick for this shape (ctx_hint = typical
+ * context length; <= 0 means unknown). */
+int mv_paged_attn_decode_pick_splits(int bs, int hkv, int ctx_hint);
+
+/* Single-token paged attention with in-kernel NeoX RoPE and KV append.
+ * For each row b with p = cache_seqlens[b]:
+ *   q,k <- bf16(RoPE(q,k) at position p) using cos/sin[p, :D/2] (skipped when cos == NULL);
+ *   k_cache/v_cache[block_table[b, p / page], p % page, h, :] <- k, v   (in place);
+ *   out[b,hq,:] = bf16( softmax(q . K[0..p]^T * scale) V[0..p] ), q head hq reading kv head hq / (Hq/Hkv),
+ *   scores/softmax/accumulate in fp32, P rounded to bf16 before P.V.
+ * q: [bs,Hq,D] (row stride q_stride_b, heads contiguous), k_new/v_new: [bs,Hkv,D]
+ * (kv_stride_b), caches: [num_pages, page, Hkv, D] contiguous, cache_seqlens: int32 [bs],
+ * block_table: int32 [bs, bt_stride] (-1 = unallocated, never dereferenced for
+ * indices <= p / page unless the caller broke the contract, in which case the key is
+ * skipped), out: [bs,Hq,D] contiguous.  D in {64,128}; Hq/Hkv in {1,2,4,8}.
+ * Replaces the flash_attn_with_kvcache call at core/layer/model_graph.py:161-168
+ * (and core/paged_attention.py:281). */
+int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, const void* v_new,
+                         int64_t kv_stride_b, void* k_cache, void* v_cache, const void* rot_cos,
+                         const void* rot_sin, int rot_max_pos, const int32_t* cache_seqlens,
+                         const int32_t* block_table, int bt_stride, void* out, void* workspace,
+                         size_t workspace_bytes, int bs, int hq, int hkv, int d, int page,
+                         int num_pages, float scale, int num_splits, mv_stream_t stream);
+
+/* key[t,h,:] -> k_cache[slot/page, slot%page, h, :] (same for value); slot -1 = skip.
+ * key/value: [T,H,D] with token stride kv_stride_t; slot_mapping int32 [T].
+ * Replaces core/cache_manager.py:143 store_kvcache (Triton store_kvcache_kernel :75). */
+int mv_store_kv(const void* key, const void* value, int64_t kv_stride_t, void* k_cache,
+                void* v_cache, const int32_t* slot_mapping, int tokens, int heads, int d,
+                int page, int num_pages, mv_stream_t stream);
+
+/* ------------------------------------------------------------ hipGraph */
+
+/* Capture everything launched on `stream` between begin and end into an
+ * executable hipGraph; replay it with mv_graph_launch.  Replaces the
+ * torch.cuda.CUDAGraph capture/replay of core/layer/model_graph.py:241-259. */
+int mv_graph_begin_capture(mv_stream_t stream);
+int mv_graph_end_capture(mv_stream_t stream, void** graph_exec_out);
+int mv_graph_launch(void* graph_exec, mv_stream_t stream);
+int mv_graph_destroy(void* graph_exec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVLLM_H */

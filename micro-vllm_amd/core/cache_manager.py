@@ -1,0 +1,195 @@
+"""Paged KV-cache bookkeeping with the reference's KVCacheManager surface
+(core/cache_manager.py:262-691): alloc / append / put / get / get_blocks / cache_batch_data /
+get_buffer_data / get_slots / free / reset / stats, plus the attributes the runners read
+directly (`k_caches`, `v_caches`, `block_size`, `_block_table_buffer`, `_cache_seqlens_buffer`).
+
+Storage is one torch tensor per K and V (sliced per layer) laid out
+[layer][page][slot][kv_head][D]; the bookkeeping is host-side integers.  The block table and
+sequence-length buffers keep fixed device addresses (they are rewritten in place each step) so
+captured graphs stay valid.
+"""
+import collections
+from typing import List
+
+import torch
+
+from .. import _native as nv
+
+
+def store_kvcache(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor,
+                  v_cache: torch.Tensor, slot_mapping: torch.Tensor, block_size: int):
+    """key/value [T,H,D] -> cache[slot // block_size, slot % block_size]; slot -1 is skipped.
+    Same contract as the reference's store_kvcache (core/cache_manager.py:143)."""
+    num_tokens, num_heads, head_size = key.shape
+    assert key.dim() == 3 and value.dim() == 3
+    assert value.shape == (num_tokens, num_heads, head_size)
+    assert slot_mapping.numel() == num_tokens
+    assert key.is_cuda, "store_kvcache runs on the GPU library only"
+    assert key.stride(2) == 1 and key.stride(1) == head_size
+    assert value.stride() == key.stride(), "key and value must share strides"
+    assert k_cache.is_contiguous() and v_cache.is_contiguous()
+    slots = slot_mapping.to(device=key.device, dtype=torch.int32).contiguous()
+    stride_t = key.stride(0) if num_tokens > 1 else num_heads * head_size
+    nv.check("mv_store_kv", nv.lib().mv_store_kv(
+        key.data_ptr(), value.data_ptr(), stride_t, k_cache.data_ptr(), v_cache.data_ptr(),
+        slots.data_ptr(), num_tokens, num_heads, head_size, block_size, k_cache.shape[0],
+        nv.stream_ptr()))
+
+
+def store_kvcache_batch(key, value, k_cache, v_cache, slot_mapping_batch, block_size):
+    """[B,1,H,D] form of store_kvcache (core/cache_manager.py:196)."""
+    batch_size, num_tokens, num_heads, head_size = key.shape
+    assert num_tokens == 1, "Only support num_tokens=1 for decoding stage"
+    assert slot_mapping_batch.shape == (batch_size, num_tokens)
+    store_kvcache(key.reshape(-1, num_heads, head_size), value.reshape(-1, num_heads, head_size),
+                  k_cache, v_cache, slot_mapping_batch.reshape(-1), block_size)
+
+
+class KVCacheManager:
+    def __init__(self, n_blocks: int, block_size: int, n_layers: int, n_heads: int, head_size: int,
+                 dtype=torch.float16, device="cuda", max_tokens: int = 1024,
+                 max_batch_size: int = 32, strict_reference: bool = False):
+        """`strict_reference=True` keeps the reference's accounting for prompts whose length is
+        an exact multiple of block_size (the last block is recorded as empty, so the next
+        page is never opened - core/cache_manager.py:384-387); the default records it as
+        full, which is what lets a sequence of 4096 tokens keep decoding."""
+        self.n_blocks, self.block_size, self.n_layers = n_blocks, block_size, n_layers
+        self.dtype, self.device = dtype, device
+        self.strict_reference = strict_reference
+
+        shape = (n_layers, n_blocks, block_size, n_heads, head_size)
+        self._k_store = torch.zeros(shape, dtype=dtype, device=device)
+        self._v_store = torch.zeros(shape, dtype=dtype, device=device)
+        self.k_caches = [self._k_store[i] for i in range(n_layers)]
+        self.v_caches = [self._v_store[i] for i in range(n_layers)]
+
+        self._free = collections.deque(range(n_blocks))
+        self._blocks = {}  # seq_id -> [block ids]
+        self._pos = {}     # block id -> used slots
+
+        self.cache_seqlens = torch.tensor([1], dtype=torch.int32, device=self.device)
+        self.max_tokens = max_tokens
+        self.max_seq_blocks = (max_tokens + block_size - 1) // block_size
+        self._block_table_buffer = torch.full((max_batch_size, self.max_seq_blocks), -1,
+                                              dtype=torch.int32, device=device)
+        self._cache_seqlens_buffer = torch.zeros(max_batch_size, dtype=torch.int32, device=device)
+        # host staging for the per-step rewrite (one copy each instead of one per row)
+        pin = torch.cuda.is_available() and str(device).startswith("cuda")
+        self._bt_host = torch.full((max_batch_size, self.max_seq_blocks), -1, dtype=torch.int32,
+                                   pin_memory=pin)
+        self._sl_host = torch.zeros(max_batch_size, dtype=torch.int32, pin_memory=pin)
+
+    # ------------------------------------------------------------------ allocation
+    def alloc(self, seq_id: int, n_tokens: int):
+        """Reserve pages for an n_tokens prompt; returns (ok, slot_mapping int32 [n_tokens])."""
+        bs = self.block_size
+        n_needed = (n_tokens + bs - 1) // bs
+        if len(self._free) < n_needed:
+            return False, None
+        blocks = [self._free.popleft() for _ in range(n_needed)]
+        for i, b in enumerate(blocks):
+            if i < n_needed - 1:
+                self._pos[b] = bs
+            else:
+                tail = n_tokens % bs
+                self._pos[b] = tail if (tail or self.strict_reference) else bs
+        self._blocks[seq_id] = blocks
+        idx = torch.arange(n_tokens, dtype=torch.int64)
+        blk = torch.tensor(blocks, dtype=torch.int64)
+        slot_mapping = (blk[idx // bs] * bs + idx % bs).to(torch.int32) if n_tokens else \
+            torch.zeros(0, dtype=torch.int32)
+        return True, slot_mapping.to(self.device)
+
+    def append(self, seq_id: int):
+        """One more token for seq_id; returns its slot or -1.  Like the reference
+        (core/cache_manager.py:401-438) a page is considered full at block_size - 1 used
+        slots, which is what keeps it in step with the engine's position numbering."""
+        if seq_id not in self._blocks:
+            return -1
+        blocks = self._blocks[seq_id]
+        last = blocks[-1]
+        used = self._pos[last]
+        if used < self.block_size - 1:
+            self._pos[last] = used + 1
+            return last * self.block_size + used
+        if self._free:
+            nb = self._free.popleft()
+            blocks.append(nb)
+            self._pos[nb] = 1
+            return nb * self.block_size
+        print(f"cache_manager.append failed for seq {seq_id}: no free block "
+              f"(blocks={blocks}, used={used}, block_size={self.block_size})")
+        return -1
+
+    def put(self, seq_id: int, key: torch.Tensor, value: torch.Tensor, layer: int,
+            slot_map: torch.Tensor):
+        store_kvcache(key, value, self.k_caches[layer], self.v_caches[layer], slot_map,
+                      self.block_size)
+
+    def get(self, layer: int, block_id: int = None):
+        k, v = self.k_caches[layer], self.v_caches[layer]
+        return (k[block_id], v[block_id]) if block_id is not None else (k, v)
+
+    def get_blocks(self, seq_id: int):
+        return self._blocks.get(seq_id, [])
+
+    # ------------------------------------------------------------------ per-step buffers
+    def cache_batch_data(self, seq_ids: list, context_lens: list):
+        """Rewrite rows [0, len(seq_ids)) of the static block table / seqlens buffers in place."""
+        n = len(seq_ids)
+        if n > 0:
+            bt = self._bt_host
+            bt[:n].fill_(-1)
+            for i, sid in enumerate(seq_ids):
+                blocks = self._blocks.get(sid, [])
+                if blocks:
+                    if len(blocks) > self.max_seq_blocks:
+                        raise RuntimeError(
+                            f"sequence {sid} spans {len(blocks)} blocks but the block table is "
+                            f"{self.max_seq_blocks} wide (max_tokens={self.max_tokens})")
+                    bt[i, :len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
+            self._sl_host[:n] = torch.tensor(context_lens, dtype=torch.int32)
+            self._block_table_buffer[:n].copy_(bt[:n], non_blocking=True)
+            self._cache_seqlens_buffer[:n].copy_(self._sl_host[:n], non_blocking=True)
+        return self._block_table_buffer[:n], self._cache_seqlens_buffer[:n]
+
+    def get_buffer_data(self, seq_ids: list):
+        n = len(seq_ids)
+        return self._block_table_buffer[:n], self._cache_seqlens_buffer[:n]
+
+    def get_slots(self, seq_id: int, token_positions: list) -> list:
+        if seq_id not in self._blocks:
+            return [-1] * len(token_positions)
+        blocks, bs = self._blocks[seq_id], self.block_size
+        out = []
+        for pos in token_positions:
+            bi, off = divmod(pos, bs)
+            if bi >= len(blocks) or off >= self._pos.get(blocks[bi], 0):
+                out.append(-1)
+            else:
+                out.append(blocks[bi] * bs + off)
+        return out
+
+    def free(self, seq_id: int):
+        blocks = self._blocks.pop(seq_id, None)
+        if blocks:
+            for b in blocks:
+                self._free.append(b)
+                self._pos.pop(b, None)
+
+    def reset(self):
+        self._free = collections.deque(range(self.n_blocks))
+        self._blocks.clear()
+        self._pos.clear()
+
+    @property
+    def stats(self):
+        total, free = self.n_blocks, len(self._free)
+        longest = run = 0
+        prev = None
+        for b in sorted(self._free):
+            run = run + 1 if (prev is not None and b == prev + 1) else 1
+            longest = max(longest, run)
+            prev = b
+        frag = 1.0 - longest / max(free, 1) if free > 0 else 0.0
+        return {"total": total, "free": free, "used": total - free, "frag": round(frag, 3)}

@@ -1,0 +1,272 @@
+"""Decode runner: one single-token forward over all layers, captured once per batch size into a
+hipGraph and replayed.  Same constructor, attributes and methods as the reference's
+ModelGraphRunner (core/layer/model_graph.py:25-260): prepare_weights / _alloc_bufs /
+_qkv_proj / _flash_attn / _ffn / decode / capture / forward.
+
+Differences that are deliberate:
+  * weights are relaid out into the wave-tile format of csrc/wgemm.hip instead of `[in,out]`;
+  * q/k/v are split as [Hq*D | Hkv*D | Hkv*D], which equals the reference's
+    `reshape(bs, 3, H, D)` when Hkv == Hq and also covers grouped-query shapes;
+  * the eager (uncaptured) path uses the real block table, not the all-zero one of
+    model_graph.py:155-159;
+  * `fused=True` (default) folds bias, SwiGLU and the final residual add into GEMM epilogues;
+    every rounding still happens where the reference's separate ops round.
+"""
+import logging
+from typing import Dict, List
+
+import torch
+
+from .. import parallel_config as pc
+from ..paged_attention import PagedAttention, paged_attn_decode
+from ... import _native as nv
+from ...kernel.linear import StreamedWeight, add_, embedding, gemm_workspace, wgemm
+from ...kernel.rmsnorm_add import rmsnorm_
+from ...kernel.rmsnorm_residual import rmsnorm_residual_gemm
+from ...kernel.swiglu import swiglu_gemm
+
+logger = logging.getLogger(__name__)
+
+
+class HipGraph:
+    """An instantiated hipGraph (mv_graph_* of the C ABI)."""
+
+    def __init__(self, handle):
+        self.handle = handle
+
+    def replay(self):
+        nv.check("mv_graph_launch", nv.lib().mv_graph_launch(self.handle, nv.stream_ptr()))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                nv.lib().mv_graph_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class ModelGraphRunner:
+    def __init__(self, model, num_layers: int, num_heads: int, head_size: int, kv_num_heads: int,
+                 hidden_dim: int, intermediate_size: int, device: str, max_batch_size: int = 32,
+                 dtype: torch.dtype = torch.bfloat16, top_k: int = 1000, fused: bool = True,
+                 max_blocks: int = 32, exact_rope: bool = False, release_source_weights: bool = False):
+        """num_heads / kv_num_heads / intermediate_size are the PER-RANK values (already divided
+        by the tensor-parallel world size), intermediate_size counting gate and up together,
+        exactly as the reference's engine passes them (core/engine.py:108-114)."""
+        assert dtype == torch.bfloat16, "the HIP path computes in bf16 storage / fp32 accumulate"
+        self.model = model
+        self.num_layers = num_layers
+        self.rank, self.world_size = pc.get_rank(), pc.get_world_size()
+        self.num_heads = num_heads
+        self.kv_num_heads = kv_num_heads
+        self.intermediate_size = intermediate_size
+        self.head_size = head_size
+        self.hidden_dim = hidden_dim
+        self.vocab_size = model.config.vocab_size
+        self.device = device
+        self.max_bs = max_batch_size
+        self.dtype = dtype
+        self.top_k = top_k
+        self.fused = fused
+        self.release_source_weights = release_source_weights
+
+        self.attention = PagedAttention(num_heads, head_size, kv_num_heads, device, max_batch_size,
+                                        max_blocks=max_blocks, exact_positions=exact_rope)
+        self.prepare_weights()
+        self._alloc_bufs()
+        self._graphs: Dict[int, HipGraph] = {}
+        self._is_graph_ready = False
+        self._num_splits: Dict[int, int] = {}
+
+    # ------------------------------------------------------------------ init
+    def prepare_weights(self):
+        """Tensor-parallel slicing as in the reference (column-parallel QKV and gate/up: rows of
+        the [out,in] weight; row-parallel O and down: its columns), then the one-time relayout
+        into wave tiles."""
+        cfg = self.model.config
+        g_heads = cfg.num_attention_heads
+        g_kv = getattr(cfg, "num_key_value_heads", g_heads)
+        q_dim, kv_dim = g_heads * self.head_size, g_kv * self.head_size
+        ws, rk = self.world_size, self.rank
+        dev = self.device
+
+        def shard0(w):
+            return w.chunk(ws, dim=0)[rk]
+
+        def shard1(w):
+            return w.chunk(ws, dim=1)[rk]
+
+        for block in self.model.transformer.h:
+            w1, w2 = block.mlp.w1.weight.to(dev), block.mlp.w2.weight.to(dev)
+            if self.fused:
+                block.mlp._gu = StreamedWeight.from_up_gate(shard0(w1), shard0(w2))
+            else:
+                block.mlp._gu = StreamedWeight.from_linear(torch.cat([shard0(w1), shard0(w2)], dim=0))
+            block.mlp._d = StreamedWeight.from_linear(shard1(block.mlp.c_proj.weight.to(dev)).contiguous())
+            block.attn._o = StreamedWeight.from_linear(shard1(block.attn.c_proj.weight.to(dev)).contiguous())
+
+            w_qkv, b_qkv = block.attn.c_attn.weight.to(dev), block.attn.c_attn.bias
+            w_q, w_k, w_v = w_qkv.split([q_dim, kv_dim, kv_dim], dim=0)
+            block.attn._qkv_w = StreamedWeight.from_linear(
+                torch.cat([shard0(w_q), shard0(w_k), shard0(w_v)], dim=0))
+            block.attn._qkv_b = None
+            if b_qkv is not None:
+                b_q, b_k, b_v = b_qkv.to(dev).split([q_dim, kv_dim, kv_dim], dim=0)
+                block.attn._qkv_b = torch.cat([shard0(b_q), shard0(b_k), shard0(b_v)], dim=0).contiguous()
+            block.ln_1.weight = block.ln_1.weight.to(dev)
+            block.ln_2.weight = block.ln_2.weight.to(dev)
+            if self.release_source_weights:
+                block.mlp.w1.weight = block.mlp.w2.weight = block.mlp.c_proj.weight = None
+                block.attn.c_attn.weight = block.attn.c_proj.weight = None
+        tr = self.model.transformer
+        tr.wte.weight = tr.wte.weight.to(dev).contiguous()
+        tr.ln_f.weight = tr.ln_f.weight.to(dev)
+        # embedding, final norm and LM head are replicated on every rank (model_graph.py:196,222-223)
+        self._lm_head = StreamedWeight.from_linear(self.model.lm_head.weight.to(dev))
+        if self.release_source_weights:
+            self.model.lm_head.weight = None
+        torch.cuda.synchronize()
+        logger.info("weights relaid out (rank %d)", self.rank)
+
+    def _alloc_bufs(self):
+        max_b, dev, dt = self.max_bs, self.device, self.dtype
+        _b = self.model.transformer.h[0]
+        qkv_dim = _b.attn._qkv_w.shape[1]
+        o_dim = _b.attn._o.shape[1]
+        self._input_ids = torch.zeros(max_b, dtype=torch.long, device=dev)
+        self._logits = torch.empty(max_b, self.vocab_size, dtype=dt, device=dev)
+        self._hidden0 = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
+        self._normed = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
+        self._qkv = torch.empty(max_b, qkv_dim, dtype=dt, device=dev)
+        self._attn = torch.empty(max_b, self.num_heads, self.head_size, dtype=dt, device=dev)
+        self._attn_out = torch.empty(max_b, o_dim, dtype=dt, device=dev)
+        self._residual = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
+        self._gate_up = torch.empty((max_b, self.intermediate_size), dtype=dt, device=dev)
+        self._swiglu_out = torch.empty((max_b, self.intermediate_size // 2), dtype=dt, device=dev)
+        self._mlp_out = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
+        # split-k slabs of the widest projection and split-KV partials: sized once, never regrown
+        L = nv.lib()
+        need = 0
+        shapes = [(qkv_dim, self.hidden_dim), (o_dim, _b.attn._o.k), (_b.mlp._gu.n, self.hidden_dim),
+                  (self.hidden_dim, _b.mlp._d.k), (self.vocab_size, self.hidden_dim)]
+        for n, k in shapes:
+            need = max(need, L.mv_wgemm_workspace_bytes(max_b, n, k))
+        self._gemm_ws = gemm_workspace(dev, max(need, 16))
+        self._attn_ws = None
+
+    # ------------------------------------------------------------------ pieces
+    def _splits_for(self, bs, cache_manager):
+        ns = self._num_splits.get(bs)
+        if ns is None:
+            ctx = cache_manager._block_table_buffer.shape[1] * cache_manager.block_size
+            ns = nv.lib().mv_paged_attn_decode_pick_splits(bs, self.kv_num_heads, ctx)
+            self._num_splits[bs] = ns
+            need = nv.lib().mv_paged_attn_decode_workspace_bytes(self.max_bs, self.num_heads,
+                                                                 self.head_size, max(ns, 2))
+            if self._attn_ws is None or self._attn_ws.numel() * 4 < need:
+                self._attn_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+        return ns
+
+    def _qkv_proj(self, h, block, bs):
+        rmsnorm_(h, block.ln_1.weight, self._normed[:bs], block.ln_1.eps)
+        qkv_buf = self._qkv[:bs]
+        if self.fused:
+            wgemm(self._normed[:bs], block.attn._qkv_w, qkv_buf, bias=block.attn._qkv_b,
+                  workspace=self._gemm_ws)
+        else:
+            wgemm(self._normed[:bs], block.attn._qkv_w, qkv_buf, workspace=self._gemm_ws)
+            if block.attn._qkv_b is not None:
+                add_(qkv_buf, block.attn._qkv_b)
+        return qkv_buf
+
+    def _flash_attn(self, qkv, block, layer_idx, bs, cache_manager, use_graph_cache=True):
+        hq, hkv, d = self.num_heads, self.kv_num_heads, self.head_size
+        q = qkv[:, :hq * d].unflatten(1, (hq, d))
+        k = qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d))
+        v = qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d))
+        k_cache, v_cache = cache_manager.get(layer_idx)
+        attn = paged_attn_decode(
+            q, k, v, k_cache, v_cache, cache_manager._cache_seqlens_buffer[:bs],
+            cache_manager._block_table_buffer[:bs], self.attention._cos_pool,
+            self.attention._sin_pool, num_splits=self._splits_for(bs, cache_manager),
+            out=self._attn[:bs], workspace=self._attn_ws)
+        out_buf = self._attn_out[:bs]
+        wgemm(attn.reshape(bs, -1), block.attn._o, out_buf, workspace=self._gemm_ws)
+        return out_buf
+
+    def _ffn(self, x_normed, block, bs, residual=None):
+        if self.fused:
+            wgemm(x_normed, block.mlp._gu, self._swiglu_out[:bs], swiglu=True, workspace=self._gemm_ws)
+        else:
+            wgemm(x_normed, block.mlp._gu, self._gate_up[:bs], workspace=self._gemm_ws)
+            swiglu_gemm(self._gate_up[:bs], self._swiglu_out[:bs])
+        wgemm(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs], residual=residual,
+              workspace=self._gemm_ws)
+        return self._mlp_out[:bs]
+
+    # ------------------------------------------------------------------ decode
+    def decode(self, input_ids, bs, cache_manager, use_graph_cache=True):
+        """One token for each of `bs` rows; returns logits [bs, V] (a view of a static buffer).
+        Allocation-free after the first call for a given bs, so it can be stream-captured."""
+        tr = self.model.transformer
+        h = embedding(tr.wte.weight, input_ids, self._hidden0[:bs])
+        fold_residual = self.fused and self.world_size == 1
+        for layer_idx in range(self.num_layers):
+            block = tr.h[layer_idx]
+            qkv = self._qkv_proj(h, block, bs)
+            attn_out = self._flash_attn(qkv, block, layer_idx, bs, cache_manager, use_graph_cache)
+            attn_out = pc.all_reduce(attn_out)
+            rmsnorm_residual_gemm(attn_out, h, block.ln_2.weight, self._normed[:bs],
+                                  self._residual[:bs], block.ln_2.eps)
+            if fold_residual:
+                h = self._ffn(self._normed[:bs], block, bs, residual=self._residual[:bs])
+            else:
+                mlp_out = self._ffn(self._normed[:bs], block, bs)
+                h = add_(pc.all_reduce(mlp_out), self._residual[:bs])
+        rmsnorm_(h, tr.ln_f.weight, self._normed[:bs], tr.ln_f.eps)
+        return wgemm(self._normed[:bs], self._lm_head, self._logits[:bs], workspace=self._gemm_ws)
+
+    def capture(self, cache_manager, batch_sizes: List[int] = [1, 2, 4, 8, 16, 32], warmup: int = 2):
+        """Capture one graph per batch size.  The static block-table / seqlens buffers are read
+        by the captured kernels at replay time, so their contents may change between replays."""
+        if self._is_graph_ready:
+            return
+        use_torch_graph = self.world_size > 1  # collectives are captured through torch's RCCL hooks
+        for bs in batch_sizes:
+            if bs > self.max_bs:
+                continue
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                # warm-up on the buffers as they are: every kernel guards its page lookups, so
+                # stale or -1 entries are skipped, never dereferenced
+                for _ in range(warmup):
+                    self.decode(self._input_ids[:bs], bs, cache_manager)
+                side.synchronize()
+                if use_torch_graph:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        self.decode(self._input_ids[:bs], bs, cache_manager)
+                    self._graphs[bs] = g
+                else:
+                    import ctypes
+                    nv.check("mv_graph_begin_capture", nv.lib().mv_graph_begin_capture(side.cuda_stream))
+                    try:
+                        self.decode(self._input_ids[:bs], bs, cache_manager)
+                    finally:
+                        handle = ctypes.c_void_p()
+                        rc = nv.lib().mv_graph_end_capture(side.cuda_stream, ctypes.byref(handle))
+                    nv.check("mv_graph_end_capture", rc)
+                    self._graphs[bs] = HipGraph(handle)
+            torch.cuda.current_stream().wait_stream(side)
+            logger.info("captured decode graph for batch size %d", bs)
+        self._is_graph_ready = True
+
+    def forward(self, input_ids: torch.Tensor, cache_manager, batch_size: int) -> torch.Tensor:
+        self._input_ids[:batch_size] = input_ids
+        g = self._graphs.get(batch_size)
+        if g is None:
+            return self.decode(self._input_ids[:batch_size], batch_size, cache_manager)
+        g.replay()
+        return self._logits[:batch_size]

@@ -1,0 +1,447 @@
+// Single-token paged attention (decode) with in-kernel NeoX RoPE and KV append.
+//
+// Bandwidth-bound dot-product kernel: each key/value row (one token, one kv head,
+// D bf16 = 2D bytes contiguous) is read exactly once by D/8 adjacent lanes, 16 B per
+// lane, so one wave instruction moves 64/(D/8) whole rows in full 128-byte lines.
+// All G = Hq/Hkv query heads that share the kv head are scored against the row
+// while it is in registers (GQA reuse: KV bytes are read once per kv head).
+//
+// Work split: workgroup = (sequence b, kv head, kv split); its 4 waves interleave
+// over the split's rows.  Every 16-lane (D=128) / 8-lane (D=64) row group keeps
+// its own online-softmax state (m, l, acc[G][8]); states meet once in LDS at the
+// end.  Splits write normalised fp32 partials + log2-sum-exp; a second small kernel
+// merges them (skipped when num_splits == 1).
+//
+// Numerics: q and k are rotated in fp32 and rounded to bf16 (k is stored rotated);
+// scores, softmax and accumulation are fp32; P is rounded to bf16 before P.V while
+// the normaliser sums the unrounded P.
+#include "common.h"
+
+namespace mv {
+
+constexpr int kAW = 4;           // waves per workgroup
+constexpr int kAT = kAW * 64;    // 256 threads
+constexpr int kAC = 4;           // row loads per wave per pipeline stage
+constexpr float kNegBig = -1.0e30f;
+
+struct AttnArgs {
+    const uint16_t* q;
+    int64_t q_stride_b;
+    const uint16_t* k_new;
+    const uint16_t* v_new;
+    int64_t kv_stride_b;
+    uint16_t* k_cache;
+    uint16_t* v_cache;
+    const uint16_t* rot_cos;
+    const uint16_t* rot_sin;
+    int rot_max_pos;
+    const int32_t* seqlens;
+    const int32_t* block_table;
+    int bt_stride;
+    uint16_t* out;
+    float* part_lse;  // [bs*Hq*nsplit]
+    float* part_o;    // [bs*Hq*nsplit*D]
+    int bs, hq, hkv;
+    int page, page_shift, num_pages;
+    float scale_log2;
+    int nsplit;
+};
+
+// sum over the LPR adjacent lanes that hold one row; every lane gets the total
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+    // xor-1, xor-2 inside quads, then mirror within 8, then mirror within 16
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    if (LPR == 16)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
+}
+
+// NeoX rotation of this lane's 8 elements (x) given the 8 elements half a head away
+// (partner) and cos/sin of the pair index; `first_half` says which side x is on.
+__device__ __forceinline__ void rope8(const uint4& x, const uint4& partner, const uint4& c,
+                                      const uint4& s, bool first_half, uint32_t (&out)[4]) {
+    const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ps[4] = {partner.x, partner.y, partner.z, partner.w};
+    const uint32_t cs[4] = {c.x, c.y, c.z, c.w}, ss[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float lo, hi;
+        if (first_half) {
+            lo = bf16_lo(xs[j]) * bf16_lo(cs[j]) - bf16_lo(ps[j]) * bf16_lo(ss[j]);
+            hi = bf16_hi(xs[j]) * bf16_hi(cs[j]) - bf16_hi(ps[j]) * bf16_hi(ss[j]);
+        } else {
+            lo = bf16_lo(xs[j]) * bf16_lo(cs[j]) + bf16_lo(ps[j]) * bf16_lo(ss[j]);
+            hi = bf16_hi(xs[j]) * bf16_hi(cs[j]) + bf16_hi(ps[j]) * bf16_hi(ss[j]);
+        }
+        out[j] = pack_bf16x2(lo, hi);
+    }
+}
+
+template <int D, int G>
+__global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
+    constexpr int LPR = D / 8;      // lanes per row
+    constexpr int RPI = 64 / LPR;   // rows per wave instruction
+    constexpr int NS = kAW * RPI;   // softmax states per workgroup
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* st_m = lds;                 // [NS][G]
+    float* st_l = lds + NS * G;        // [NS][G]
+    float* st_acc = lds + 2 * NS * G;  // [NS][G][D]
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane % LPR, tg = lane / LPR;
+    const int d0 = lr * 8;
+
+    const int split = blockIdx.x % a.nsplit;
+    const int bh = blockIdx.x / a.nsplit;
+    const int kvh = bh % a.hkv, b = bh / a.hkv;
+    const bool last_split = (split == a.nsplit - 1);
+
+    const int pos = a.seqlens[b];  // keys 0..pos-1 are cached, the new key lands at pos
+    const int32_t* bt = a.block_table + (int64_t)b * a.bt_stride;
+
+    // rows of this split: [t0, t1) of the cached keys
+    int tps = (pos + a.nsplit - 1) / a.nsplit;
+    tps = (tps + NS - 1) / NS * NS;
+    const int t0 = min(pos, split * tps), t1 = min(pos, t0 + tps);
+
+    // ---- q (G heads) and the new k/v: load, rotate, round ----------------------
+    const bool rotate = (a.rot_cos != nullptr);
+    const bool first_half = d0 < D / 2;
+    uint4 cosv = make_uint4(0, 0, 0, 0), sinv = cosv;
+    if (rotate) {
+        const int rp = min(max(pos, 0), a.rot_max_pos - 1);
+        const int64_t ro = (int64_t)rp * (D / 2) + (first_half ? d0 : d0 - D / 2);
+        cosv = ld16(a.rot_cos + ro);
+        sinv = ld16(a.rot_sin + ro);
+    }
+    const int dpart = first_half ? d0 + D / 2 : d0 - D / 2;
+    uint32_t qp[G][4];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const uint16_t* qh = a.q + (int64_t)b * a.q_stride_b + (int64_t)(kvh * G + g) * D;
+        const uint4 x = ld16(qh + d0);
+        if (rotate) {
+            rope8(x, ld16(qh + dpart), cosv, sinv, first_half, qp[g]);
+        } else {
+            qp[g][0] = x.x; qp[g][1] = x.y; qp[g][2] = x.z; qp[g][3] = x.w;
+        }
+    }
+    uint32_t kp[4];
+    uint4 vnew;
+    {
+        const uint16_t* kh = a.k_new + (int64_t)b * a.kv_stride_b + (int64_t)kvh * D;
+        const uint16_t* vh = a.v_new + (int64_t)b * a.kv_stride_b + (int64_t)kvh * D;
+        const uint4 x = ld16(kh + d0);
+        if (rotate) {
+            rope8(x, ld16(kh + dpart), cosv, sinv, first_half, kp);
+        } else {
+            kp[0] = x.x; kp[1] = x.y; kp[2] = x.z; kp[3] = x.w;
+        }
+        vnew = ld16(vh + d0);
+    }
+    // append: the last split owns the new row; one row group writes it
+    if (last_split && wid == 0 && tg == 0) {
+        const int pi = pos >> a.page_shift;
+        if (pos >= 0 && pi < a.bt_stride) {
+            const int pg = bt[pi];
+            if (pg >= 0 && pg < a.num_pages) {
+                const int64_t off =
+                    (((int64_t)pg << a.page_shift) + (pos & (a.page - 1))) * a.hkv * D + (int64_t)kvh * D + d0;
+                st16(a.k_cache + off, make_uint4(kp[0], kp[1], kp[2], kp[3]));
+                st16(a.v_cache + off, vnew);
+            }
+        }
+    }
+
+    // ---- online softmax state of this row group ---------------------------------
+    float m[G], l[G], acc[G][8];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        m[g] = kNegBig;
+        l[g] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[g][j] = 0.f;
+    }
+
+    // scores of up to kAC rows + their values -> state
+    auto absorb = [&](const uint4(&kb)[kAC], const uint4(&vb)[kAC], const bool(&ok)[kAC]) {
+        float s[kAC][G];
+#pragma unroll
+        for (int i = 0; i < kAC; ++i) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                float d = 0.f;
+                d = dot2_bf16(qp[g][0], kb[i].x, d);
+                d = dot2_bf16(qp[g][1], kb[i].y, d);
+                d = dot2_bf16(qp[g][2], kb[i].z, d);
+                d = dot2_bf16(qp[g][3], kb[i].w, d);
+                s[i][g] = row_sum<LPR>(d) * a.scale_log2;
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            float mx = m[g];
+#pragma unroll
+            for (int i = 0; i < kAC; ++i) mx = ok[i] ? fmaxf(mx, s[i][g]) : mx;
+            const float alpha = __builtin_amdgcn_exp2f(m[g] - mx);
+            m[g] = mx;
+            float p[kAC], psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < kAC; ++i) {
+                p[i] = ok[i] ? __builtin_amdgcn_exp2f(s[i][g] - mx) : 0.f;
+                psum += p[i];
+                p[i] = round_bf16(p[i]);
+            }
+            l[g] = l[g] * alpha + psum;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[g][j] *= alpha;
+#pragma unroll
+            for (int i = 0; i < kAC; ++i) {
+                const uint32_t vs[4] = {vb[i].x, vb[i].y, vb[i].z, vb[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[g][2 * j] = __builtin_fmaf(p[i], bf16_lo(vs[j]), acc[g][2 * j]);
+                    acc[g][2 * j + 1] = __builtin_fmaf(p[i], bf16_hi(vs[j]), acc[g][2 * j + 1]);
+                }
+            }
+        }
+    };
+
+    // ---- stream the cached rows: page ids two stages ahead, rows one stage ahead --
+    const int n_instr = (t1 - t0 + NS - 1) / NS;            // row loads of this wave
+    const int nchunk = (n_instr + kAC - 1) / kAC;
+    const int64_t head_off = (int64_t)kvh * D + d0;
+    const int64_t row_stride = (int64_t)a.hkv * D;
+
+    auto row_of = [&](int c, int i) { return t0 + ((c * kAC + i) * kAW + wid) * RPI + tg; };
+    auto load_pages = [&](int (&pg)[kAC], int c) {
+#pragma unroll
+        for (int i = 0; i < kAC; ++i) {
+            const int t = min(row_of(c, i), t1 - 1);
+            pg[i] = bt[t >> a.page_shift];
+        }
+    };
+    auto load_rows = [&](uint4(&kb)[kAC], uint4(&vb)[kAC], bool(&ok)[kAC], const int (&pg)[kAC], int c) {
+#pragma unroll
+        for (int i = 0; i < kAC; ++i) {
+            const int tr = row_of(c, i);
+            const int t = min(tr, t1 - 1);
+            const bool page_ok = pg[i] >= 0 && pg[i] < a.num_pages;
+            ok[i] = (tr < t1) && page_ok;
+            const int64_t off =
+                (((int64_t)(page_ok ? pg[i] : 0) << a.page_shift) + (t & (a.page - 1))) * row_stride + head_off;
+            kb[i] = ld16(a.k_cache + off);
+            vb[i] = ld16(a.v_cache + off);
+        }
+    };
+
+    if (nchunk > 0) {
+        uint4 kA[kAC], vA[kAC], kB[kAC], vB[kAC];
+        bool okA[kAC], okB[kAC];
+        int pgA[kAC], pgB[kAC];
+        load_pages(pgA, 0);
+        if (nchunk > 1) load_pages(pgB, 1);
+        load_rows(kA, vA, okA, pgA, 0);
+        for (int c = 0; c < nchunk; c += 2) {
+            if (c + 2 < nchunk) load_pages(pgA, c + 2);
+            if (c + 1 < nchunk) load_rows(kB, vB, okB, pgB, c + 1);
+            absorb(kA, vA, okA);
+            if (c + 3 < nchunk) load_pages(pgB, c + 3);
+            if (c + 2 < nchunk) load_rows(kA, vA, okA, pgA, c + 2);
+            if (c + 1 < nchunk) absorb(kB, vB, okB);
+        }
+    }
+
+    // ---- the new row (held in registers; never read back from the cache) --------
+    {
+        uint4 kb[kAC], vb[kAC];
+        bool ok[kAC];
+#pragma unroll
+        for (int i = 0; i < kAC; ++i) {
+            kb[i] = make_uint4(kp[0], kp[1], kp[2], kp[3]);
+            vb[i] = vnew;
+            ok[i] = false;
+        }
+        ok[0] = last_split && wid == 0 && tg == 0;
+        if (last_split && wid == 0) absorb(kb, vb, ok);  // wave-uniform branch
+    }
+
+    // ---- merge the NS states ----------------------------------------------------
+    const int sidx = wid * RPI + tg;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (lr == 0) {
+            st_m[sidx * G + g] = m[g];
+            st_l[sidx * G + g] = l[g];
+        }
+        float* dst = st_acc + ((int64_t)(sidx * G + g)) * D + d0;
+        *reinterpret_cast<f32x4_t*>(dst) = (f32x4_t){acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
+        *reinterpret_cast<f32x4_t*>(dst + 4) = (f32x4_t){acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < G * D; o += kAT) {
+        const int g = o / D, d = o - g * D;
+        float mx = kNegBig;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mx = fmaxf(mx, st_m[s * G + g]);
+        float lt = 0.f, at = 0.f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float w = __builtin_amdgcn_exp2f(st_m[s * G + g] - mx);
+            lt = __builtin_fmaf(st_l[s * G + g], w, lt);
+            at = __builtin_fmaf(st_acc[(int64_t)(s * G + g) * D + d], w, at);
+        }
+        const int hq = kvh * G + g;
+        const float val = lt > 0.f ? at / lt : 0.f;
+        if (a.nsplit == 1) {
+            a.out[((int64_t)b * a.hq + hq) * D + d] = (uint16_t)f32_to_bf16_bits(val);
+        } else {
+            const int64_t pi = ((int64_t)b * a.hq + hq) * a.nsplit + split;
+            a.part_o[pi * D + d] = val;
+            if (d == 0) a.part_lse[pi] = lt > 0.f ? mx + __builtin_amdgcn_logf(lt) : kNegBig;
+        }
+    }
+}
+
+// out[b,h,:] = sum_s w_s o_s / sum_s w_s,  w_s = 2^(lse_s - max lse)
+template <int D>
+__global__ __launch_bounds__(D) void paged_attn_combine_kernel(const float* __restrict__ part_lse,
+                                                               const float* __restrict__ part_o,
+                                                               uint16_t* __restrict__ out,
+                                                               int nsplit) {
+    const int64_t bh = blockIdx.x;
+    const int d = threadIdx.x;
+    const float* lse = part_lse + bh * nsplit;
+    float mx = kNegBig;
+    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, lse[s]);
+    float wsum = 0.f, o = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float w = __builtin_amdgcn_exp2f(lse[s] - mx);
+        wsum += w;
+        o = __builtin_fmaf(w, part_o[(bh * nsplit + s) * D + d], o);
+    }
+    out[bh * D + d] = (uint16_t)f32_to_bf16_bits(wsum > 0.f ? o / wsum : 0.f);
+}
+
+template <int D, int G>
+static int launch_decode(const AttnArgs& a, hipStream_t s) {
+    constexpr int NS = kAW * (64 / (D / 8));
+    const size_t lds = (size_t)(2 * NS * G + NS * G * D) * sizeof(float);
+    static bool configured = false;
+    if (lds > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)paged_attn_decode_kernel<D, G>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_last_hip_error(e);
+            return MV_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((paged_attn_decode_kernel<D, G>), dim3(a.bs * a.hkv * a.nsplit), dim3(kAT),
+                       lds, s, a);
+    int rc = check_launch();
+    if (rc != MV_OK || a.nsplit == 1) return rc;
+    hipLaunchKernelGGL((paged_attn_combine_kernel<D>), dim3(a.bs * a.hq), dim3(D), 0, s,
+                       a.part_lse, a.part_o, a.out, a.nsplit);
+    return check_launch();
+}
+
+template <int D>
+static int dispatch_g(const AttnArgs& a, int g, hipStream_t s) {
+    switch (g) {
+        case 1: return launch_decode<D, 1>(a, s);
+        case 2: return launch_decode<D, 2>(a, s);
+        case 4: return launch_decode<D, 4>(a, s);
+        case 8: return launch_decode<D, 8>(a, s);
+        default: return MV_ERR_UNSUPPORTED;
+    }
+}
+
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace mv
+
+extern "C" {
+
+size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_splits) {
+    if (bs <= 0 || hq <= 0 || d <= 0 || num_splits <= 1) return 0;
+    const size_t rows = (size_t)bs * hq * num_splits;
+    return mv::align_up(rows * sizeof(float), 256) + rows * d * sizeof(float);
+}
+
+int mv_paged_attn_decode_pick_splits(int bs, int hkv, int ctx_hint) {
+    if (bs <= 0 || hkv <= 0) return 1;
+    const int target = 2 * mv::num_cus();
+    int ns = (target + bs * hkv - 1) / (bs * hkv);
+    if (ctx_hint > 0) {
+        const int cap = ctx_hint / 64 > 1 ? ctx_hint / 64 : 1;  // at least 64 rows per split
+        if (ns > cap) ns = cap;
+    }
+    if (ns > 128) ns = 128;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+
+int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, const void* v_new,
+                         int64_t kv_stride_b, void* k_cache, void* v_cache, const void* rot_cos,
+                         const void* rot_sin, int rot_max_pos, const int32_t* cache_seqlens,
+                         const int32_t* block_table, int bt_stride, void* out, void* workspace,
+                         size_t workspace_bytes, int bs, int hq, int hkv, int d, int page,
+                         int num_pages, float scale, int num_splits, mv_stream_t stream) {
+    using namespace mv;
+    if (!q || !k_new || !v_new || !k_cache || !v_cache || !cache_seqlens || !block_table || !out)
+        return MV_ERR_INVALID_ARG;
+    if (bs <= 0 || hq <= 0 || hkv <= 0 || page <= 0 || num_pages <= 0 || bt_stride <= 0 ||
+        num_splits <= 0)
+        return MV_ERR_INVALID_ARG;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return MV_ERR_INVALID_ARG;
+    if (rot_cos && rot_max_pos <= 0) return MV_ERR_INVALID_ARG;
+    if (d != 64 && d != 128) return MV_ERR_UNSUPPORTED;
+    if (hq % hkv) return MV_ERR_UNSUPPORTED;
+    if (page & (page - 1)) return MV_ERR_UNSUPPORTED;  // rows are located with shifts
+    if (!aligned16(q) || !aligned16(k_new) || !aligned16(v_new) || !aligned16(k_cache) ||
+        !aligned16(v_cache) || !aligned16(out) || (q_stride_b % 8) || (kv_stride_b % 8))
+        return MV_ERR_INVALID_ARG;
+    if (rot_cos && (!aligned16(rot_cos) || !aligned16(rot_sin))) return MV_ERR_INVALID_ARG;
+
+    AttnArgs a;
+    a.q = (const uint16_t*)q;
+    a.q_stride_b = q_stride_b;
+    a.k_new = (const uint16_t*)k_new;
+    a.v_new = (const uint16_t*)v_new;
+    a.kv_stride_b = kv_stride_b;
+    a.k_cache = (uint16_t*)k_cache;
+    a.v_cache = (uint16_t*)v_cache;
+    a.rot_cos = (const uint16_t*)rot_cos;
+    a.rot_sin = (const uint16_t*)rot_sin;
+    a.rot_max_pos = rot_max_pos;
+    a.seqlens = cache_seqlens;
+    a.block_table = block_table;
+    a.bt_stride = bt_stride;
+    a.out = (uint16_t*)out;
+    a.bs = bs;
+    a.hq = hq;
+    a.hkv = hkv;
+    a.page = page;
+    a.page_shift = __builtin_ctz((unsigned)page);
+    a.num_pages = num_pages;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    a.nsplit = num_splits;
+    a.part_lse = nullptr;
+    a.part_o = nullptr;
+    if (num_splits > 1) {
+        const size_t need = mv_paged_attn_decode_workspace_bytes(bs, hq, d, num_splits);
+        if (!workspace || workspace_bytes < need || !aligned16(workspace)) return MV_ERR_WORKSPACE;
+        const size_t rows = (size_t)bs * hq * num_splits;
+        a.part_lse = (float*)workspace;
+        a.part_o = (float*)((char*)workspace + align_up(rows * sizeof(float), 256));
+    }
+    const int g = hq / hkv;
+    hipStream_t s = (hipStream_t)stream;
+    return d == 128 ? dispatch_g<128>(a, g, s) : dispatch_g<64>(a, g, s);
+}
+
+}  // extern "C"

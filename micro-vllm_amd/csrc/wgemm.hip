@@ -1,0 +1,471 @@
+// Weight-streaming skinny GEMM for decode:  y[M,N] = x[M,K] @ W[N,K]^T,  1 <= M <= 64.
+//
+// The op is HBM-bound on W (2*N*K bytes read once; x and y are M/N-th of that), so
+// the whole design serves one goal: every CU keeps >= 64 KiB of perfectly coalesced
+// weight loads in flight, and every CU gets the same number of bytes.
+//
+//  * W is stored as wave tiles (mv_shuffle_weight): tile (nt,kt) = 16 output rows x
+//    32 k = 1 KiB, lane l owning W[16nt + (l&15)][32kt + 8(l>>4) + 0..7].  One
+//    global_load_dwordx4 per wave moves one tile and leaves it already laid out as
+//    the A operand of v_mfma_f32_16x16x32_bf16 (rows on lanes&15, k on lanes>>4).
+//    The tiles of one 16-row strip are contiguous along K.
+//  * A unit of work is (strip nt, k-slice ks).  A 512-thread workgroup takes whole
+//    units; its 8 waves interleave over the unit's tiles (wave w takes tile kt0+w,
+//    kt0+w+8, ...) so the workgroup reads one contiguous stream.  Partial sums of
+//    the 8 waves meet in LDS in a fixed order: results are run-to-run identical.
+//  * M <= 4: dot-product form (v_dot2c_f32_bf16), x staged once per workgroup in
+//    LDS.  M > 4: v_mfma_f32_16x16x32_bf16 with the x fragment (B operand) loaded
+//    from L2 in the same lane layout.  Both read the same weight tiles.
+//  * ksplit > 1 (picked when strips alone cannot balance the CUs) writes fp32
+//    slabs; a small second kernel adds them in slab order and applies the epilogue.
+//
+// Epilogue rounding follows the reference's op boundaries: t = bf16(acc);
+// t = bf16(t + bias); t = bf16(t + residual); SWIGLU: out = bf16(silu(gate_t) * up_t).
+#include "common.h"
+
+namespace mv {
+
+constexpr int kGW = 8;               // waves per workgroup
+constexpr int kGT = kGW * kWave;     // 512 threads
+constexpr int kU = 8;                // tiles per wave per pipeline stage
+constexpr int kMaxKsplit = 8;
+
+static int g_tune_bpc = 2;      // workgroups per CU the grid is sized for
+static int g_tune_ksplit = 0;   // 0 = heuristic
+
+struct GemmArgs {
+    const uint16_t* x;
+    int64_t ldx;
+    const uint4* w;
+    const uint16_t* bias;
+    const uint16_t* residual;
+    int64_t ld_res;
+    void* y;
+    int64_t ldy;
+    float* partial;  // [ksplit][M][N] fp32 when ksplit > 1
+    int m, n, k;
+    int nt, kt;      // strips, k-tiles per strip
+    int ksplit, ktps;  // k-slices, k-tiles per slice
+    int nunits;
+    int flags;
+};
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+__device__ __forceinline__ float silu_mul_rounded(float gate_acc, float up_acc) {
+    const float g = round_bf16(gate_acc), u = round_bf16(up_acc);
+    const float sig = 1.0f / (1.0f + expf(-g));
+    return (g * sig) * u;
+}
+
+// Final value of one output element from its fp32 accumulator.
+__device__ __forceinline__ float epilogue_value(const GemmArgs& a, float acc, int m, int n) {
+    float t = round_bf16(acc);
+    if (a.bias) t = round_bf16(t + bf16_bits_to_f32(a.bias[n]));
+    if (a.residual) t = round_bf16(t + bf16_bits_to_f32(a.residual[(int64_t)m * a.ld_res + n]));
+    return t;
+}
+
+// ------------------------------------------------------------ M <= 4: dot form
+template <int M>
+__global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // layout: x rows [M][K] bf16 | 16 zero bytes | red [kGW][M][16] fp32
+    uint16_t* xs = reinterpret_cast<uint16_t*>(smem);
+    const int zero_off = M * a.k * 2;
+    float* red = reinterpret_cast<float*>(smem + zero_off + 16);
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+
+    // stage x (previous kernel's output; L2 resident) while nothing else is pending
+    {
+        const int kvec = a.k >> 3;
+        for (int c = threadIdx.x; c < M * kvec; c += kGT) {
+            const int m = c / kvec, cv = c - m * kvec;
+            st16(xs + m * a.k + cv * 8, ld16(a.x + (int64_t)m * a.ldx + cv * 8));
+        }
+        if (threadIdx.x == 0) *reinterpret_cast<uint4*>(smem + zero_off) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+
+    for (int u = blockIdx.x; u < a.nunits; u += gridDim.x) {
+        const int nt = u / a.ksplit, ks = u - nt * a.ksplit;
+        const int kt0 = ks * a.ktps;
+        const int kt1 = min(a.kt, kt0 + a.ktps);
+        const int ntile = (kt1 - kt0 - wid + kGW - 1) / kGW;  // tiles of this wave (may be <= 0)
+        const uint4* wbase = a.w + ((int64_t)nt * a.kt + kt0 + wid) * 64 + lane;
+        const int last = max(ntile - 1, 0);
+
+        float acc[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) acc[m] = 0.f;
+
+        uint4 bufA[kU], bufB[kU];
+        auto load = [&](uint4(&buf)[kU], int c) {
+#pragma unroll
+            for (int i = 0; i < kU; ++i) {
+                const int t = min(c * kU + i, last);  // clamp: always a valid address
+                buf[i] = ld16_nt(wbase + (int64_t)t * (kGW * 64));
+            }
+        };
+        auto compute = [&](const uint4(&buf)[kU], int c) {
+#pragma unroll
+            for (int i = 0; i < kU; ++i) {
+                const int t = c * kU + i;
+                // byte offset of this lane's 8 x values; out-of-range tiles read zeros
+                const int xoff = (t < ntile) ? ((kt0 + wid + t * kGW) * 32 + q * 8) * 2 : -1;
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    const int off = (xoff < 0) ? zero_off : m * a.k * 2 + xoff;
+                    const uint4 xv = *reinterpret_cast<const uint4*>(smem + off);
+                    acc[m] = dot2_bf16(buf[i].x, xv.x, acc[m]);
+                    acc[m] = dot2_bf16(buf[i].y, xv.y, acc[m]);
+                    acc[m] = dot2_bf16(buf[i].z, xv.z, acc[m]);
+                    acc[m] = dot2_bf16(buf[i].w, xv.w, acc[m]);
+                }
+            }
+        };
+
+        const int nchunk = (ntile + kU - 1) / kU;
+        if (nchunk > 0) load(bufA, 0);
+        for (int c = 0; c < nchunk; c += 2) {
+            if (c + 1 < nchunk) load(bufB, c + 1);
+            compute(bufA, c);
+            if (c + 2 < nchunk) load(bufA, c + 2);
+            if (c + 1 < nchunk) compute(bufB, c + 1);
+        }
+
+        // lanes r, r+16, r+32, r+48 hold the four k-quarters of row r
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            acc[m] += __shfl_xor(acc[m], 16, 64);
+            acc[m] += __shfl_xor(acc[m], 32, 64);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) red[(wid * M + m) * 16 + r] = acc[m];
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 * M) {
+            const int m = threadIdx.x >> 4, rr = threadIdx.x & 15;
+            float s = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < kGW; ++w8) s += red[(w8 * M + m) * 16 + rr];
+            const int n = nt * 16 + rr;
+            if (a.ksplit > 1) {
+                a.partial[((int64_t)ks * a.m + m) * a.n + n] = s;
+            } else if (a.flags & MV_GEMM_OUT_F32) {
+                reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n] = s;
+            } else if (a.flags & MV_GEMM_SWIGLU) {
+                if (rr < 8) {
+                    float g = 0.f;
+#pragma unroll
+                    for (int w8 = 0; w8 < kGW; ++w8) g += red[(w8 * M + m) * 16 + rr + 8];
+                    reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + nt * 8 + rr] =
+                        (uint16_t)f32_to_bf16_bits(silu_mul_rounded(g, s));
+                }
+            } else {
+                reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + n] =
+                    (uint16_t)f32_to_bf16_bits(epilogue_value(a, s, m, n));
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------ M > 4: MFMA form
+// MB = number of 16-row blocks of x (M <= 16*MB).
+template <int MB>
+__global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
+    constexpr int U = (MB <= 2) ? 4 : 2;  // tiles per stage (register budget)
+    __shared__ __attribute__((aligned(16))) float red[kGW * MB * 64 * 4];
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+
+    // this lane's x rows (B operand column), clamped into [0, M)
+    const uint16_t* xrow[MB];
+#pragma unroll
+    for (int b = 0; b < MB; ++b) xrow[b] = a.x + (int64_t)min(b * 16 + r, a.m - 1) * a.ldx + q * 8;
+
+    for (int u = blockIdx.x; u < a.nunits; u += gridDim.x) {
+        const int nt = u / a.ksplit, ks = u - nt * a.ksplit;
+        const int kt0 = ks * a.ktps;
+        const int kt1 = min(a.kt, kt0 + a.ktps);
+        const int ntile = (kt1 - kt0 - wid + kGW - 1) / kGW;
+        const uint4* wbase = a.w + ((int64_t)nt * a.kt + kt0 + wid) * 64 + lane;
+        const int last = max(ntile - 1, 0);
+
+        f32x4_t acc[MB];
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        uint4 wA[U], wB[U], xA[U][MB], xB[U][MB];
+        auto load = [&](uint4(&wb)[U], uint4(&xb)[U][MB], int c) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                const int t = min(c * U + i, last);
+                wb[i] = ld16_nt(wbase + (int64_t)t * (kGW * 64));
+                const int kcol = (kt0 + wid + t * kGW) * 32;
+#pragma unroll
+                for (int b = 0; b < MB; ++b) xb[i][b] = ld16(xrow[b] + kcol);
+            }
+        };
+        auto compute = [&](const uint4(&wb)[U], const uint4(&xb)[U][MB], int c) {
+#pragma unroll
+            for (int i = 0; i < U; ++i) {
+                if (c * U + i < ntile) {  // wave-uniform
+                    const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wb[i]);
+#pragma unroll
+                    for (int b = 0; b < MB; ++b)
+                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            wf, __builtin_bit_cast(bf16x8_t, xb[i][b]), acc[b], 0, 0, 0);
+                }
+            }
+        };
+
+        const int nchunk = (ntile + U - 1) / U;
+        if (nchunk > 0) load(wA, xA, 0);
+        for (int c = 0; c < nchunk; c += 2) {
+            if (c + 1 < nchunk) load(wB, xB, c + 1);
+            compute(wA, xA, c);
+            if (c + 2 < nchunk) load(wA, xA, c + 2);
+            if (c + 1 < nchunk) compute(wB, xB, c + 1);
+        }
+
+        // acc[b][j] = C[n = 4q + j][m = 16b + r]
+#pragma unroll
+        for (int b = 0; b < MB; ++b)
+            *reinterpret_cast<f32x4_t*>(&red[((wid * MB + b) * 64 + lane) * 4]) = acc[b];
+        __syncthreads();
+        if (threadIdx.x < 64 * MB) {
+            const int b = threadIdx.x >> 6, l = threadIdx.x & 63;
+            const int rr = l & 15, qq = l >> 4;
+            const int m = b * 16 + rr;
+            auto sum_at = [&](int ll) {
+                f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int w8 = 0; w8 < kGW; ++w8)
+                    s += *reinterpret_cast<const f32x4_t*>(&red[((w8 * MB + b) * 64 + ll) * 4]);
+                return s;
+            };
+            if (m < a.m) {
+                const f32x4_t s = sum_at(l);
+                const int n0 = nt * 16 + qq * 4;
+                if (a.ksplit > 1) {
+                    *reinterpret_cast<f32x4_t*>(&a.partial[((int64_t)ks * a.m + m) * a.n + n0]) = s;
+                } else if (a.flags & MV_GEMM_OUT_F32) {
+                    *reinterpret_cast<f32x4_t*>(
+                        &reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n0]) = s;
+                } else if (a.flags & MV_GEMM_SWIGLU) {
+                    if (qq < 2) {  // rows 0..7 = up; their gates sit 8 rows (32 lanes) further
+                        const f32x4_t g = sum_at(l + 32);
+                        uint2 o;
+                        o.x = pack_bf16x2(silu_mul_rounded(g[0], s[0]), silu_mul_rounded(g[1], s[1]));
+                        o.y = pack_bf16x2(silu_mul_rounded(g[2], s[2]), silu_mul_rounded(g[3], s[3]));
+                        *reinterpret_cast<uint2*>(&reinterpret_cast<uint16_t*>(
+                            a.y)[(int64_t)m * a.ldy + nt * 8 + qq * 4]) = o;
+                    }
+                } else {
+                    uint2 o;
+                    o.x = pack_bf16x2(epilogue_value(a, s[0], m, n0), epilogue_value(a, s[1], m, n0 + 1));
+                    o.y = pack_bf16x2(epilogue_value(a, s[2], m, n0 + 2), epilogue_value(a, s[3], m, n0 + 3));
+                    *reinterpret_cast<uint2*>(
+                        &reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + n0]) = o;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------ slab reduction
+// One thread per output element (per up/gate pair for SWIGLU); slabs added in order.
+__global__ __launch_bounds__(256) void wgemm_finalize_kernel(GemmArgs a) {
+    const bool sw = (a.flags & MV_GEMM_SWIGLU) != 0;
+    const int ncols = sw ? a.n / 2 : a.n;
+    const int64_t total = (int64_t)a.m * ncols;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * 256) {
+        const int m = (int)(i / ncols), c = (int)(i - (int64_t)m * ncols);
+        auto slab_sum = [&](int n) {
+            float s = 0.f;
+            for (int ks = 0; ks < a.ksplit; ++ks) s += a.partial[((int64_t)ks * a.m + m) * a.n + n];
+            return s;
+        };
+        if (sw) {
+            const int nu = (c >> 3) * 16 + (c & 7);
+            const float up = slab_sum(nu), gate = slab_sum(nu + 8);
+            reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + c] =
+                (uint16_t)f32_to_bf16_bits(silu_mul_rounded(gate, up));
+        } else if (a.flags & MV_GEMM_OUT_F32) {
+            reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + c] = slab_sum(c);
+        } else {
+            reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + c] =
+                (uint16_t)f32_to_bf16_bits(epilogue_value(a, slab_sum(c), m, c));
+        }
+    }
+}
+
+// ------------------------------------------------------------ host planning
+// k-slices per strip: balance whole units over the CUs.  Cost in tiles per CU,
+// with a split paying roughly one extra kernel boundary.
+static int pick_ksplit(int nt, int kt) {
+    if (g_tune_ksplit > 0) {
+        int ks = g_tune_ksplit;
+        while (ks > 1 && (kt % ks) != 0) --ks;
+        return ks;
+    }
+    const int cus = num_cus();
+    int best = 1;
+    long best_cost = -1;
+    for (int ks = 1; ks <= kMaxKsplit; ks *= 2) {
+        if (kt % ks) break;
+        const int ktps = kt / ks;
+        if (ks > 1 && ktps < 2 * kGW) break;
+        const long rounds = ((long)nt * ks + cus - 1) / cus;
+        const long cost = rounds * ktps + (ks > 1 ? 40 : 0);
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = ks;
+        }
+    }
+    return best;
+}
+
+template <int M>
+static int launch_dot(const GemmArgs& a, int grid, hipStream_t s) {
+    const size_t lds = (size_t)M * a.k * 2 + 16 + (size_t)kGW * M * 16 * 4;
+    if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
+    static size_t configured = 0;  // per instantiation
+    if (lds > 64 * 1024 && lds > configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgemm_dot_kernel<M>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) {
+            set_last_hip_error(e);
+            return MV_ERR_LAUNCH;
+        }
+        configured = 160 * 1024;
+    }
+    hipLaunchKernelGGL(wgemm_dot_kernel<M>, dim3(grid), dim3(kGT), lds, s, a);
+    return check_launch();
+}
+
+template <int MB>
+static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL(wgemm_mfma_kernel<MB>, dim3(grid), dim3(kGT), 0, s, a);
+    return check_launch();
+}
+
+}  // namespace mv
+
+extern "C" {
+
+// Tuning hook for experiments: key 0 = workgroups per CU, key 1 = forced ksplit (0 = auto).
+int mv_wgemm_tune(int key, int value) {
+    if (key == 0 && value >= 1 && value <= 8) {
+        mv::g_tune_bpc = value;
+        return MV_OK;
+    }
+    if (key == 1 && value >= 0 && value <= mv::kMaxKsplit) {
+        mv::g_tune_ksplit = value;
+        return MV_OK;
+    }
+    return MV_ERR_INVALID_ARG;
+}
+
+size_t mv_wgemm_workspace_bytes(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
+    // slabs for the split the planner picks now; a call that later finds the
+    // workspace too small (tuning changed) runs unsplit instead of failing
+    const int ks = mv::pick_ksplit(n / 16, k / 32);
+    return ks > 1 ? (size_t)ks * (size_t)m * (size_t)n * sizeof(float) : 0;
+}
+
+int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
+             const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n, int k,
+             void* workspace, size_t workspace_bytes, int flags, mv_stream_t stream) {
+    using namespace mv;
+    if (!x || !w_tiles || !y || m <= 0 || n <= 0 || k <= 0) return MV_ERR_INVALID_ARG;
+    if (m > 64 || (n % 16) != 0 || (k % 32) != 0) return MV_ERR_UNSUPPORTED;
+    if (!aligned16(x) || !aligned16(w_tiles) || (ldx % 8) != 0 || ldx < k) return MV_ERR_INVALID_ARG;
+    const bool sw = (flags & MV_GEMM_SWIGLU) != 0, of32 = (flags & MV_GEMM_OUT_F32) != 0;
+    if (sw && (bias || residual || of32)) return MV_ERR_UNSUPPORTED;
+    if (of32 && (bias || residual)) return MV_ERR_UNSUPPORTED;
+    const int ncols = sw ? n / 2 : n;
+    if (ldy < ncols) return MV_ERR_INVALID_ARG;
+    if (!of32 && ((reinterpret_cast<uintptr_t>(y) & 7) != 0 || (ldy % 4) != 0))
+        return MV_ERR_INVALID_ARG;
+    if (of32 && (!aligned16(y) || (ldy % 4) != 0)) return MV_ERR_INVALID_ARG;
+    if (residual && ld_res < n) return MV_ERR_INVALID_ARG;
+
+    GemmArgs a;
+    a.x = (const uint16_t*)x;
+    a.ldx = ldx;
+    a.w = (const uint4*)w_tiles;
+    a.bias = (const uint16_t*)bias;
+    a.residual = (const uint16_t*)residual;
+    a.ld_res = ld_res;
+    a.y = y;
+    a.ldy = ldy;
+    a.m = m;
+    a.n = n;
+    a.k = k;
+    a.nt = n / 16;
+    a.kt = k / 32;
+    a.ksplit = pick_ksplit(a.nt, a.kt);
+    a.partial = nullptr;
+    if (a.ksplit > 1) {
+        const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
+        if (!workspace || workspace_bytes < need || !aligned16(workspace)) {
+            a.ksplit = 1;  // no room for slabs: fall back to whole strips (slower, same result class)
+        } else {
+            a.partial = (float*)workspace;
+        }
+    }
+    a.ktps = a.kt / a.ksplit;
+    a.nunits = a.nt * a.ksplit;
+    a.flags = flags;
+
+    const int cus = num_cus();
+    // LDS of the dot form limits co-residency; never size the grid past what fits
+    int bpc = g_tune_bpc;
+    if (m <= 4) {
+        const size_t lds = (size_t)m * k * 2 + 16 + (size_t)kGW * m * 64;
+        const int fit = (int)((160 * 1024) / (lds + 512));
+        if (fit < 1) return MV_ERR_UNSUPPORTED;
+        if (bpc > fit) bpc = fit;
+    }
+    if (bpc > 4) bpc = 4;  // 4 x 512 threads = 32 waves per CU
+    int grid = a.nunits < cus * bpc ? a.nunits : cus * bpc;
+    hipStream_t s = (hipStream_t)stream;
+
+    int rc;
+    switch (m) {
+        case 1: rc = launch_dot<1>(a, grid, s); break;
+        case 2: rc = launch_dot<2>(a, grid, s); break;
+        case 3: rc = launch_dot<3>(a, grid, s); break;
+        case 4: rc = launch_dot<4>(a, grid, s); break;
+        default: {
+            const int mb = (m + 15) / 16;
+            if (mb == 1) rc = launch_mfma<1>(a, grid, s);
+            else if (mb == 2) rc = launch_mfma<2>(a, grid, s);
+            else if (mb == 3) rc = launch_mfma<3>(a, grid, s);
+            else rc = launch_mfma<4>(a, grid, s);
+        }
+    }
+    if (rc != MV_OK) return rc;
+    if (a.ksplit > 1) {
+        const int64_t total = (int64_t)m * ncols;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > cus * 4) blocks = cus * 4;
+        hipLaunchKernelGGL(wgemm_finalize_kernel, dim3(blocks), dim3(256), 0, s, a);
+        rc = check_launch();
+    }
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+"""Decode-time projections: weights kept in the wave-tile layout the HIP skinny GEMM streams.
+
+Stands in for the pre-transposed `[in,out]` weights plus `torch.matmul(..., out=)` calls of
+the reference's decode runner (core/layer/model_graph.py:87-118, :145, :171, :183-185, :223).
+"""
+from typing import Optional
+
+import torch
+
+from .. import _native as nv
+
+
+class StreamedWeight:
+    """A Linear weight ([N,K], y = x @ W^T) relaid out once into 16x32 wave tiles.
+
+    `swiglu=True` means rows are up/gate interleaved in groups of 8 (built by
+    `from_up_gate`), so `wgemm(..., swiglu=True)` can apply SiLU(gate)*up in the epilogue.
+    """
+
+    def __init__(self, tiles: torch.Tensor, n: int, k: int, swiglu: bool = False):
+        self.tiles, self.n, self.k, self.swiglu = tiles, n, k, swiglu
+
+    @property
+    def out_features(self) -> int:
+        return self.n // 2 if self.swiglu else self.n
+
+    @property
+    def shape(self):
+        """(in, out) like the reference's transposed weights, e.g. `_qkv_w.shape[1]`."""
+        return (self.k, self.n)
+
+    @property
+    def nbytes(self) -> int:
+        return self.n * self.k * 2
+
+    @classmethod
+    def from_linear(cls, w_nk: torch.Tensor) -> "StreamedWeight":
+        assert w_nk.is_cuda and w_nk.dtype == torch.bfloat16 and w_nk.dim() == 2
+        w_nk = w_nk.contiguous()
+        n, k = w_nk.shape
+        assert n % 16 == 0 and k % 32 == 0, f"weight {n}x{k}: need N%16==0 and K%32==0"
+        tiles = torch.empty(n * k, dtype=torch.bfloat16, device=w_nk.device)
+        nv.check("mv_shuffle_weight", nv.lib().mv_shuffle_weight(
+            w_nk.data_ptr(), tiles.data_ptr(), n, k, nv.stream_ptr()))
+        return cls(tiles, n, k, False)
+
+    @classmethod
+    def from_up_gate(cls, up: torch.Tensor, gate: torch.Tensor) -> "StreamedWeight":
+        """up, gate: [I,K] each (the reference's mlp.w1 / mlp.w2 shards)."""
+        assert up.shape == gate.shape and up.is_cuda and up.dtype == torch.bfloat16
+        up, gate = up.contiguous(), gate.contiguous()
+        i, k = up.shape
+        assert i % 8 == 0 and k % 32 == 0
+        inter = torch.empty(2 * i, k, dtype=torch.bfloat16, device=up.device)
+        nv.check("mv_interleave_rows8", nv.lib().mv_interleave_rows8(
+            up.data_ptr(), gate.data_ptr(), inter.data_ptr(), i, k, nv.stream_ptr()))
+        sw = cls.from_linear(inter)
+        sw.swiglu = True
+        return sw
+
+
+_workspaces = {}
+
+
+def gemm_workspace(device, nbytes: int) -> Optional[torch.Tensor]:
+    """One grow-only fp32 slab buffer per device (k-split partial sums)."""
+    if nbytes <= 0:
+        return None
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def wgemm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
+          bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+          swiglu: bool = False, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x @ W^T (+ bias) (+ residual), or swiglu(x @ W^T) when `swiglu`.
+
+    x: [M,K] bf16, out: [M,N] bf16 (or fp32 for the un-rounded accumulators), M <= 64.
+    Every optional term rounds to bf16 where the reference's separate ops round.
+    """
+    assert x.is_cuda and out.is_cuda and x.dtype == torch.bfloat16
+    assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
+    m, k = x.shape
+    assert k == w.k, f"K mismatch: {k} vs {w.k}"
+    assert swiglu == w.swiglu, "weight layout and epilogue disagree"
+    ncols = w.out_features
+    assert out.shape == (m, ncols), f"Output shape mismatch: {tuple(out.shape)} vs {(m, ncols)}"
+    flags = nv.MV_GEMM_SWIGLU if swiglu else nv.MV_GEMM_DEFAULT
+    if out.dtype == torch.float32:
+        flags |= nv.MV_GEMM_OUT_F32
+    else:
+        assert out.dtype == torch.bfloat16
+    if bias is not None:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == w.n and bias.is_contiguous()
+    ld_res = 0
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape == (m, w.n) and residual.stride(1) == 1
+        ld_res = residual.stride(0) if m > 1 else w.n
+    L = nv.lib()
+    if workspace is None:
+        workspace = gemm_workspace(x.device, L.mv_wgemm_workspace_bytes(m, w.n, k))
+    ws_ptr = workspace.data_ptr() if workspace is not None else None
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    ldx = x.stride(0) if m > 1 else max(k, x.stride(0))
+    ldy = out.stride(0) if m > 1 else max(ncols, out.stride(0))
+    nv.check("mv_wgemm", L.mv_wgemm(
+        x.data_ptr(), ldx, w.tiles.data_ptr(), nv.ptr(bias), nv.ptr(residual), ld_res,
+        out.data_ptr(), ldy, m, w.n, k, ws_ptr, ws_bytes, flags, nv.stream_ptr()))
+    return out
+
+
+def embedding(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[r] = table[ids[r]] (model.transformer.wte(input_ids), model_graph.py:196)."""
+    assert table.is_cuda and ids.is_cuda and out.is_cuda
+    assert table.dtype == torch.bfloat16 and out.dtype == torch.bfloat16 and ids.dtype == torch.long
+    assert table.is_contiguous() and out.is_contiguous() and ids.is_contiguous()
+    rows = ids.numel()
+    vocab, n = table.shape
+    assert out.shape[-1] == n and out.numel() == rows * n
+    nv.check("mv_embedding", nv.lib().mv_embedding(
+        table.data_ptr(), ids.data_ptr(), out.data_ptr(), rows, n, vocab, nv.stream_ptr()))
+    return out
+
+
+def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a += b in bf16 (b may be a bias row broadcast over a's rows)."""
+    assert a.is_cuda and b.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16
+    assert a.is_contiguous() and b.is_contiguous()
+    nv.check("mv_add", nv.lib().mv_add(a.data_ptr(), b.data_ptr(), a.data_ptr(), a.numel(),
+                                       b.numel(), nv.stream_ptr()))
+    return a

@@ -1,0 +1,71 @@
+"""The product KVCacheManager's integer bookkeeping against traces recorded from the reference's own
+KVCacheManager (tests/golden/cache_traces.json).  Runs on CPU tensors: no kernel is involved."""
+import json
+import os
+
+import pytest
+import torch
+
+from test_oracle_golden import _replay
+
+
+def make(mv, tr, strict):
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+
+    return KVCacheManager(tr["n_blocks"], tr["block_size"], 1, 1, 8, dtype=torch.float32,
+                          device="cpu", max_tokens=tr["max_tokens"],
+                          max_batch_size=tr["max_batch_size"], strict_reference=strict)
+
+
+def test_block_tables_bit_exact_vs_reference(mv, golden_dir):
+    traces = json.load(open(os.path.join(golden_dir, "cache_traces.json")))
+    for tr in traces:
+        _replay(tr, make(mv, tr, strict=True), is_ref=False)
+
+
+def test_default_mode_matches_reference_off_the_page_boundary(mv, golden_dir):
+    """With the page-boundary fix on (default), every trace whose prompt length is not a multiple
+    of the block size is still identical to the reference."""
+    traces = json.load(open(os.path.join(golden_dir, "cache_traces.json")))
+    for tr in traces:
+        if tr["name"].startswith("degenerate"):
+            continue
+        _replay(tr, make(mv, tr, strict=False), is_ref=False)
+
+
+@pytest.mark.parametrize("L", [256, 4096])
+def test_full_last_page_opens_the_next_one(mv, L):
+    """Prompt of exactly k pages: the reference records the last page as empty and never opens the
+    next, leaving block_table[L // 256] = -1 where the first decoded token is written.  The default
+    mode opens it on the first append."""
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+
+    mgr = KVCacheManager(40, 256, 1, 1, 8, dtype=torch.float32, device="cpu", max_tokens=8192,
+                         max_batch_size=2)
+    ok, slots = mgr.alloc(1, L)
+    assert ok and slots.numel() == L
+    mgr.append(1)
+    bt, sl = mgr.cache_batch_data([1], [L + 1])
+    assert int(bt[0, (L + 1) // 256]) >= 0
+    assert sl.tolist() == [L + 1]
+
+
+def test_oom_and_table_width(mv):
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+
+    mgr = KVCacheManager(4, 16, 1, 1, 8, dtype=torch.float32, device="cpu", max_tokens=32,
+                         max_batch_size=2)
+    assert mgr._block_table_buffer.shape == (2, 2)
+    ok, _ = mgr.alloc(1, 100)
+    assert not ok
+    ok, _ = mgr.alloc(1, 48)  # 3 pages, table is 2 wide
+    assert ok
+    with pytest.raises(RuntimeError):
+        mgr.cache_batch_data([1], [48])
+    assert mgr.append(99) == -1
+    mgr.free(1)
+    assert mgr.stats == {"total": 4, "free": 4, "used": 0, "frag": 0.0}
+    a = mgr._block_table_buffer.data_ptr()
+    mgr.alloc(2, 5)
+    mgr.cache_batch_data([2], [5])
+    assert mgr._block_table_buffer.data_ptr() == a  # static address

@@ -1,0 +1,155 @@
+"""Paged decode attention (mv_paged_attn_decode) against the CPU restatement of
+flash_attn_with_kvcache.  PARITY UNPINNED at the reference level (third-party kernel, no golden
+vector upstream): the oracle restates the documented contract.  Block-table indexing and the KV
+append are checked bit-exact; attention outputs to atol 1e-3 + one bf16 unit in the last place."""
+import pytest
+import torch
+
+from conftest import assert_close_bf16
+from oracle.ref_attention import flash_attn_with_kvcache_ref
+from oracle.ref_ops import rotary_tables_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def make_case(B, Hq, Hkv, D, page, ctxs, seed, n_pages=None, rotary=True, pad_cols=2):
+    """Random cache pre-filled for `ctxs` tokens per row through a shuffled block table."""
+    g = torch.Generator().manual_seed(seed)
+    need = [(c + 1 + page - 1) // page for c in ctxs]
+    n_pages = n_pages or (sum(need) + 3)
+    perm = torch.randperm(n_pages, generator=g).tolist()
+    width = max(need) + pad_cols
+    bt = torch.full((B, width), -1, dtype=torch.int32)
+    it = iter(perm)
+    for b in range(B):
+        for i in range(need[b]):
+            bt[b, i] = next(it)
+    k_cache = torch.randn(n_pages, page, Hkv, D, generator=g).to(torch.bfloat16)
+    v_cache = torch.randn(n_pages, page, Hkv, D, generator=g).to(torch.bfloat16)
+    q = torch.randn(B, 1, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, 1, Hkv, D, generator=g).to(torch.bfloat16)
+    v = torch.randn(B, 1, Hkv, D, generator=g).to(torch.bfloat16)
+    seqlens = torch.tensor(ctxs, dtype=torch.int32)
+    cos = sin = None
+    if rotary:
+        cos, sin = rotary_tables_ref(D, 32 * 256)
+    return dict(q=q, k=k, v=v, k_cache=k_cache, v_cache=v_cache, bt=bt, seqlens=seqlens, cos=cos, sin=sin)
+
+
+def run_both(case, num_splits=0):
+    from micro_vllm_amd.core.paged_attention import flash_attn_with_kvcache
+
+    kc_ref, vc_ref = case["k_cache"].clone(), case["v_cache"].clone()
+    want = flash_attn_with_kvcache_ref(case["q"], kc_ref, vc_ref, case["k"], case["v"], case["cos"],
+                                       case["sin"], case["seqlens"], case["bt"], causal=True)
+    kc, vc = case["k_cache"].to(DEV), case["v_cache"].to(DEV)
+    to = lambda t: None if t is None else t.to(DEV)
+    got = flash_attn_with_kvcache(
+        q=case["q"].to(DEV), k_cache=kc, v_cache=vc, k=case["k"].to(DEV), v=case["v"].to(DEV),
+        rotary_cos=to(case["cos"]), rotary_sin=to(case["sin"]), cache_seqlens=case["seqlens"].to(DEV),
+        block_table=case["bt"].to(DEV), causal=True, window_size=(-1, -1), rotary_interleaved=False,
+        alibi_slopes=None, num_splits=num_splits)
+    return got, want, (kc, vc), (kc_ref, vc_ref)
+
+
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 2), (128, 4, 4), (128, 8, 1), (128, 4, 2),
+                                      (64, 8, 2), (64, 8, 1), (64, 4, 4), (64, 2, 1)])
+@pytest.mark.parametrize("splits", [1, 3, 0])
+def test_decode_attention_vs_oracle(mv, D, Hq, Hkv, splits):
+    ctxs = [0, 1, 15, 16, 17, 255, 256, 257, 700]
+    case = make_case(len(ctxs), Hq, Hkv, D, 256, ctxs, seed=D + Hq * 3 + Hkv)
+    got, want, (kc, vc), (kc_ref, vc_ref) = run_both(case, splits)
+    assert got.shape == (len(ctxs), 1, Hq, D)
+    assert_close_bf16(got, want, what=f"attn D={D} Hq={Hq} Hkv={Hkv} splits={splits}")
+    # the appended row (rotated k, raw v) and every untouched slot: bit exact
+    assert torch.equal(vc.cpu(), vc_ref)
+    assert torch.equal(kc.cpu(), kc_ref)
+
+
+def test_small_pages_many_blocks_and_long_context(mv):
+    """page=16 exercises block_table gathering on nearly every row load; ctx 4095 / 4096."""
+    for page, ctxs in [(16, [5, 100, 333, 47]), (256, [4095, 4096])]:
+        case = make_case(len(ctxs), 8, 2, 128, page, ctxs, seed=page)
+        for splits in (1, 8, 0):
+            got, want, (kc, vc), (kc_ref, vc_ref) = run_both(case, splits)
+            assert_close_bf16(got, want, what=f"page={page} splits={splits}")
+            assert torch.equal(kc.cpu(), kc_ref) and torch.equal(vc.cpu(), vc_ref)
+
+
+def test_duplicate_rows_write_the_same_slot(mv):
+    """The scheduler pads decode batches by repeating sequences (core/scheduler.py:88-92): rows
+    with one block table and position write identical KV into one slot and agree on the output."""
+    case = make_case(1, 8, 2, 128, 256, [300], seed=5)
+    for key in ("q", "k", "v", "bt", "seqlens"):
+        case[key] = case[key].repeat(4, *([1] * (case[key].dim() - 1)))
+    got, want, (kc, vc), (kc_ref, vc_ref) = run_both(case, 0)
+    assert_close_bf16(got, want)
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[3])
+    assert torch.equal(kc.cpu(), kc_ref) and torch.equal(vc.cpu(), vc_ref)
+
+
+def test_no_rotary_and_custom_scale(mv):
+    from micro_vllm_amd.core.paged_attention import paged_attn_decode
+
+    case = make_case(3, 4, 2, 64, 256, [10, 200, 513], seed=8, rotary=False)
+    kc_ref, vc_ref = case["k_cache"].clone(), case["v_cache"].clone()
+    want = flash_attn_with_kvcache_ref(case["q"], kc_ref, vc_ref, case["k"], case["v"], None, None,
+                                       case["seqlens"], case["bt"], softmax_scale=0.2)
+    kc, vc = case["k_cache"].to(DEV), case["v_cache"].to(DEV)
+    got = paged_attn_decode(case["q"][:, 0].to(DEV), case["k"][:, 0].to(DEV), case["v"][:, 0].to(DEV),
+                            kc, vc, case["seqlens"].to(DEV), case["bt"].to(DEV), softmax_scale=0.2)
+    assert_close_bf16(got, want[:, 0])
+    assert torch.equal(kc.cpu(), kc_ref)
+
+
+def test_unallocated_page_is_skipped_not_dereferenced(mv):
+    """A -1 entry where the new token should land (the reference's own allocator produces this for
+    prompts of exactly k pages) must not fault: the write is dropped and the key ignored."""
+    case = make_case(2, 4, 2, 128, 256, [256, 100], seed=13)
+    case["bt"][0, 1] = -1
+    kc, vc = case["k_cache"].to(DEV), case["v_cache"].to(DEV)
+    from micro_vllm_amd.core.paged_attention import paged_attn_decode
+    got = paged_attn_decode(case["q"][:, 0].to(DEV), case["k"][:, 0].to(DEV), case["v"][:, 0].to(DEV),
+                            kc, vc, case["seqlens"].to(DEV), case["bt"].to(DEV),
+                            case["cos"].to(DEV), case["sin"].to(DEV))
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    # row 1 is unaffected and still matches the oracle
+    kc_ref, vc_ref = case["k_cache"].clone(), case["v_cache"].clone()
+    want = flash_attn_with_kvcache_ref(case["q"][1:], kc_ref, vc_ref, case["k"][1:], case["v"][1:],
+                                       case["cos"], case["sin"], case["seqlens"][1:], case["bt"][1:])
+    assert_close_bf16(got[1], want[0, 0])
+
+
+def test_strided_qkv_views(mv):
+    """q/k/v as views of one fused [B, (Hq+2Hkv)D] projection row, as the runner passes them."""
+    from micro_vllm_amd.core.paged_attention import paged_attn_decode
+
+    B, Hq, Hkv, D = 5, 8, 2, 128
+    case = make_case(B, Hq, Hkv, D, 256, [3, 64, 65, 1000, 511], seed=21)
+    qkv = torch.cat([case["q"][:, 0].reshape(B, -1), case["k"][:, 0].reshape(B, -1),
+                     case["v"][:, 0].reshape(B, -1)], dim=1).to(DEV)
+    q = qkv[:, :Hq * D].unflatten(1, (Hq, D))
+    k = qkv[:, Hq * D:(Hq + Hkv) * D].unflatten(1, (Hkv, D))
+    v = qkv[:, (Hq + Hkv) * D:].unflatten(1, (Hkv, D))
+    kc, vc = case["k_cache"].to(DEV), case["v_cache"].to(DEV)
+    got = paged_attn_decode(q, k, v, kc, vc, case["seqlens"].to(DEV), case["bt"].to(DEV),
+                            case["cos"].to(DEV), case["sin"].to(DEV))
+    kc_ref, vc_ref = case["k_cache"].clone(), case["v_cache"].clone()
+    want = flash_attn_with_kvcache_ref(case["q"], kc_ref, vc_ref, case["k"], case["v"], case["cos"],
+                                       case["sin"], case["seqlens"], case["bt"])
+    assert_close_bf16(got, want[:, 0])
+    assert torch.equal(kc.cpu(), kc_ref)
+
+
+def test_softmax_spike_forces_rescale(mv):
+    """One key far above the rest, late in the sequence: the running maximum must jump and every
+    earlier accumulator be rescaled."""
+    case = make_case(1, 4, 1, 128, 256, [900], seed=33, rotary=False)
+    pg = int(case["bt"][0, 850 // 256])
+    case["k_cache"][pg, 850 % 256, 0] = case["q"][0, 0, 1] * 3.0
+    got, want, _, _ = run_both(case, 1)
+    assert_close_bf16(got, want, what="spike, 1 split")
+    got, want, _, _ = run_both(case, 5)
+    assert_close_bf16(got, want, what="spike, 5 splits")

@@ -1,0 +1,143 @@
+"""Weight-streaming skinny GEMM (mv_wgemm) against the CPU oracle's linear_ref / swiglu_ref."""
+import pytest
+import torch
+
+from conftest import assert_close_bf16, ulp_diff
+from oracle.ref_ops import linear_ref, swiglu_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mk(m, n, k, seed, scale=0.05):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) * scale).to(torch.bfloat16)
+    return x, w, g
+
+
+def test_tile_layout_is_what_the_header_says(mv):
+    """tile (nt,kt), lane l, element j  <-  W[16nt + (l&15)][32kt + 8(l>>4) + j]."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight
+
+    n, k = 48, 96
+    w = torch.arange(n * k, dtype=torch.float32).reshape(n, k)
+    w = (w % 251).to(torch.bfloat16)  # exactly representable, asymmetric
+    tiles = StreamedWeight.from_linear(w.to(DEV)).tiles.cpu().reshape(n // 16, k // 32, 64, 8)
+    want = w.reshape(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).reshape(n // 16, k // 32, 64, 8)
+    assert torch.equal(tiles, want)
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4, 5, 8, 16, 17, 32, 33, 64])
+@pytest.mark.parametrize("n,k", [(64, 128), (272, 2048), (4096, 4096)])
+def test_wgemm_vs_oracle(mv, m, n, k):
+    from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm
+
+    x, w, _ = _mk(m, n, k, seed=m * 7 + n + k)
+    sw = StreamedWeight.from_linear(w.to(DEV))
+    # un-rounded accumulators: fp32 sums of exact bf16 products, only the order differs
+    acc = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.float32, device=DEV))
+    want32 = x.float() @ w.float().t()
+    assert (acc.cpu() - want32).abs().max().item() <= 1e-4 * max(1.0, want32.abs().max().item())
+    y = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
+    want = linear_ref(x, w)
+    assert ulp_diff(y, want).max() <= 1
+    assert float((ulp_diff(y, want) == 0).float().mean()) > 0.99
+    assert_close_bf16(y, want, what=f"wgemm m={m} n={n} k={k}")
+
+
+@pytest.mark.parametrize("m", [1, 4, 6, 32])
+def test_wgemm_bias_and_residual_rounding_points(mv, m):
+    """bf16(bf16(bf16(acc) + bias) + residual): the reference's matmul(out=), .add_(bias), .add_(res)."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm
+
+    n, k = 512, 1024
+    x, w, g = _mk(m, n, k, seed=40 + m)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16)
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16)
+    sw = StreamedWeight.from_linear(w.to(DEV))
+    y = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV),
+              bias=bias.to(DEV), residual=res.to(DEV))
+    base = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV)).cpu()
+    # given the kernel's own bf16(acc), the two adds must be bit exact
+    want = ((base.float() + bias.float()).to(torch.bfloat16).float() + res.float()).to(torch.bfloat16)
+    assert torch.equal(y.cpu(), want)
+    assert_close_bf16(y, (linear_ref(x, w, bias).float() + res.float()).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("m", [1, 3, 8, 32])
+def test_wgemm_swiglu_epilogue_equals_separate_ops(mv, m):
+    """Fused gate/up GEMM + SwiGLU == matmul -> swiglu_gemm (model_graph.py:183-184), bit for bit."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm
+    from micro_vllm_amd.kernel.swiglu import swiglu_gemm
+
+    inter, k = 704, 512
+    g = torch.Generator().manual_seed(60 + m)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    up = (torch.randn(inter, k, generator=g) * 0.05).to(torch.bfloat16)
+    gate = (torch.randn(inter, k, generator=g) * 0.05).to(torch.bfloat16)
+    fused_w = StreamedWeight.from_up_gate(up.to(DEV), gate.to(DEV))
+    plain_w = StreamedWeight.from_linear(torch.cat([up, gate], 0).to(DEV))
+    fused = wgemm(x.to(DEV), fused_w, torch.empty(m, inter, dtype=torch.bfloat16, device=DEV), swiglu=True)
+    gu = wgemm(x.to(DEV), plain_w, torch.empty(m, 2 * inter, dtype=torch.bfloat16, device=DEV))
+    sep = swiglu_gemm(gu, torch.empty(m, inter, dtype=torch.bfloat16, device=DEV))
+    assert torch.equal(fused, sep)
+    want = swiglu_ref(linear_ref(x, torch.cat([up, gate], 0)))
+    assert_close_bf16(fused, want, what="fused swiglu")
+
+
+def test_wgemm_ksplit_variants_agree_and_are_deterministic(mv):
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm
+
+    m, n, k = 2, 6144, 4096
+    x, w, _ = _mk(m, n, k, seed=77)
+    sw = StreamedWeight.from_linear(w.to(DEV))
+    want = linear_ref(x, w)
+    outs = []
+    try:
+        for ks in (1, 2, 4, 8):
+            assert nv.lib().mv_wgemm_tune(1, ks) == 0
+            y1 = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
+            y2 = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
+            assert torch.equal(y1, y2), f"ksplit {ks}: run-to-run difference"
+            assert ulp_diff(y1, want).max() <= 1
+            outs.append(y1)
+        for bpc in (1, 2, 4):
+            assert nv.lib().mv_wgemm_tune(0, bpc) == 0
+            y = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
+            assert ulp_diff(y, want).max() <= 1
+    finally:
+        nv.lib().mv_wgemm_tune(1, 0)
+        nv.lib().mv_wgemm_tune(0, 2)
+
+
+def test_wgemm_strided_rows_and_big_k(mv):
+    """x and y rows taken from wider static buffers; K = 14336 (the down projection)."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm
+
+    m, n, k = 3, 256, 14336
+    x, w, _ = _mk(m, n, k, seed=91, scale=0.02)
+    xb = torch.zeros(8, k + 64, dtype=torch.bfloat16, device=DEV)
+    xb[:m, :k] = x.to(DEV)
+    yb = torch.full((8, n + 32), 7.0, dtype=torch.bfloat16, device=DEV)
+    sw = StreamedWeight.from_linear(w.to(DEV))
+    wgemm(xb[:m, :k], sw, yb[:m, :n])
+    assert_close_bf16(yb[:m, :n], linear_ref(x, w))
+    assert (yb[m:] == 7).all() and (yb[:, n:] == 7).all()
+
+
+def test_wgemm_rejects_bad_shapes(mv):
+    from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm
+
+    x, w, _ = _mk(2, 64, 128, seed=1)
+    sw = StreamedWeight.from_linear(w.to(DEV))
+    with pytest.raises(AssertionError):
+        wgemm(x.to(DEV)[:, :96], sw, torch.empty(2, 64, dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(AssertionError):
+        wgemm(x.to(DEV), sw, torch.empty(2, 48, dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(AssertionError):
+        StreamedWeight.from_linear(torch.zeros(60, 128, dtype=torch.bfloat16, device=DEV))
+    big = torch.zeros(65, 128, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(AssertionError):
+        wgemm(big, sw, torch.empty(65, 64, dtype=torch.bfloat16, device=DEV))
