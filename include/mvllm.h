@@ -123,7 +123,7 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int ctx_hint);
  *   q,k <- bf16(RoPE(q,k) at position p) using cos/sin[p, :D/2] (skipped when cos == NULL);
  *   k_cache/v_cache[block_table[b, p / page], p % page, h, :] <- k, v   (in place);
  *   out[b,hq,:] = bf16( softmax(q . K[0..p]^T * scale) V[0..p] ), q head hq reading kv head hq / (Hq/Hkv),
- *   scores/softmax/accumulate in fp32, P rounded to bf16 before P.V.
+ *   scores, softmax, P and the P.V accumulation in fp32.
  * q: [bs,Hq,D] (row stride q_stride_b, heads contiguous), k_new/v_new: [bs,Hkv,D]
  * (kv_stride_b), caches: [num_pages, page, Hkv, D] contiguous, cache_seqlens: int32 [bs],
  * block_table: int32 [bs, bt_stride] (-1 = unallocated, never dereferenced for

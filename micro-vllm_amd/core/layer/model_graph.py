@@ -206,26 +206,34 @@ class ModelGraphRunner:
         return self._mlp_out[:bs]
 
     # ------------------------------------------------------------------ decode
+    def _layer(self, h, layer_idx, bs, cache_manager):
+        """One transformer block on hidden state `h` [bs, hid]; returns the next hidden state
+        (a view of a static buffer)."""
+        block = self.model.transformer.h[layer_idx]
+        qkv = self._qkv_proj(h, block, bs)
+        attn_out = self._flash_attn(qkv, block, layer_idx, bs, cache_manager)
+        attn_out = pc.all_reduce(attn_out)
+        rmsnorm_residual_gemm(attn_out, h, block.ln_2.weight, self._normed[:bs],
+                              self._residual[:bs], block.ln_2.eps)
+        if self.fused and self.world_size == 1:
+            return self._ffn(self._normed[:bs], block, bs, residual=self._residual[:bs])
+        mlp_out = self._ffn(self._normed[:bs], block, bs)
+        return add_(pc.all_reduce(mlp_out), self._residual[:bs])
+
+    def _head(self, h, bs, out=None):
+        """Final norm + LM head; `out` may be an fp32 [bs,V] tensor to get un-rounded logits."""
+        tr = self.model.transformer
+        rmsnorm_(h, tr.ln_f.weight, self._normed[:bs], tr.ln_f.eps)
+        return wgemm(self._normed[:bs], self._lm_head, self._logits[:bs] if out is None else out,
+                     workspace=self._gemm_ws)
+
     def decode(self, input_ids, bs, cache_manager, use_graph_cache=True):
         """One token for each of `bs` rows; returns logits [bs, V] (a view of a static buffer).
         Allocation-free after the first call for a given bs, so it can be stream-captured."""
-        tr = self.model.transformer
-        h = embedding(tr.wte.weight, input_ids, self._hidden0[:bs])
-        fold_residual = self.fused and self.world_size == 1
+        h = embedding(self.model.transformer.wte.weight, input_ids, self._hidden0[:bs])
         for layer_idx in range(self.num_layers):
-            block = tr.h[layer_idx]
-            qkv = self._qkv_proj(h, block, bs)
-            attn_out = self._flash_attn(qkv, block, layer_idx, bs, cache_manager, use_graph_cache)
-            attn_out = pc.all_reduce(attn_out)
-            rmsnorm_residual_gemm(attn_out, h, block.ln_2.weight, self._normed[:bs],
-                                  self._residual[:bs], block.ln_2.eps)
-            if fold_residual:
-                h = self._ffn(self._normed[:bs], block, bs, residual=self._residual[:bs])
-            else:
-                mlp_out = self._ffn(self._normed[:bs], block, bs)
-                h = add_(pc.all_reduce(mlp_out), self._residual[:bs])
-        rmsnorm_(h, tr.ln_f.weight, self._normed[:bs], tr.ln_f.eps)
-        return wgemm(self._normed[:bs], self._lm_head, self._logits[:bs], workspace=self._gemm_ws)
+            h = self._layer(h, layer_idx, bs, cache_manager)
+        return self._head(h, bs)
 
     def capture(self, cache_manager, batch_sizes: List[int] = [1, 2, 4, 8, 16, 32], warmup: int = 2):
         """Capture one graph per batch size.  The static block-table / seqlens buffers are read

@@ -13,8 +13,9 @@
 // merges them (skipped when num_splits == 1).
 //
 // Numerics: q and k are rotated in fp32 and rounded to bf16 (k is stored rotated);
-// scores, softmax and accumulation are fp32; P is rounded to bf16 before P.V while
-// the normaliser sums the unrounded P.
+// scores, softmax, P and the P.V accumulation are all fp32.  (A tensor-core kernel
+// rounds P to bf16 to feed the matrix unit; a dot-product kernel has no reason to,
+// and keeping P exact halves the expected distance to any such kernel's result.)
 #include "common.h"
 
 namespace mv {
@@ -193,7 +194,6 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
             for (int i = 0; i < kAC; ++i) {
                 p[i] = ok[i] ? __builtin_amdgcn_exp2f(s[i][g] - mx) : 0.f;
                 psum += p[i];
-                p[i] = round_bf16(p[i]);
             }
             l[g] = l[g] * alpha + psum;
 #pragma unroll

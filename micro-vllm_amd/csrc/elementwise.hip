@@ -122,8 +122,8 @@ static int ew_grid(int64_t work_items) {
 extern "C" {
 
 int mv_swiglu(const void* gate_up, void* out, int64_t rows, int d, mv_stream_t stream) {
+    if (rows == 0 && d > 0) return MV_OK;
     if (!gate_up || !out || rows < 0 || d <= 0) return MV_ERR_INVALID_ARG;
-    if (rows == 0) return MV_OK;
     if ((d % 8) == 0 && mv::aligned16(gate_up) && mv::aligned16(out)) {
         const int64_t nvec = rows * (int64_t)(d / 8);
         hipLaunchKernelGGL(mv::swiglu_kernel, dim3(mv::ew_grid(nvec)), dim3(mv::kEwThreads), 0,
@@ -139,8 +139,8 @@ int mv_swiglu(const void* gate_up, void* out, int64_t rows, int d, mv_stream_t s
 }
 
 int mv_add(const void* a, const void* b, void* out, int64_t n, int64_t n_b, mv_stream_t stream) {
+    if (n == 0 && n_b > 0) return MV_OK;
     if (!a || !b || !out || n < 0 || n_b <= 0) return MV_ERR_INVALID_ARG;
-    if (n == 0) return MV_OK;
     if ((n % n_b) != 0 || (n_b % 8) != 0) return MV_ERR_UNSUPPORTED;
     if (!mv::aligned16(a) || !mv::aligned16(b) || !mv::aligned16(out)) return MV_ERR_INVALID_ARG;
     hipLaunchKernelGGL(mv::add_kernel, dim3(mv::ew_grid(n / 8)), dim3(mv::kEwThreads), 0,
@@ -151,8 +151,8 @@ int mv_add(const void* a, const void* b, void* out, int64_t n, int64_t n_b, mv_s
 
 int mv_embedding(const void* table, const int64_t* ids, void* out, int rows, int n, int64_t vocab,
                  mv_stream_t stream) {
+    if (rows == 0 && n > 0) return MV_OK;
     if (!table || !ids || !out || rows < 0 || n <= 0 || vocab <= 0) return MV_ERR_INVALID_ARG;
-    if (rows == 0) return MV_OK;
     if ((n % 8) != 0) return MV_ERR_UNSUPPORTED;
     if (!mv::aligned16(table) || !mv::aligned16(out)) return MV_ERR_INVALID_ARG;
     hipLaunchKernelGGL(mv::embedding_kernel, dim3(rows), dim3(mv::kEwThreads), 0,

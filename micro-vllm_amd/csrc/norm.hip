@@ -92,8 +92,8 @@ extern "C" {
 
 int mv_rmsnorm(const void* x, const void* w, void* y, int rows, int n, int64_t stride_x,
                int64_t stride_y, float eps, mv_stream_t stream) {
+    if (rows == 0 && n > 0) return MV_OK;  // nothing to do (empty tensors carry null pointers)
     if (!x || !w || !y || rows < 0 || n <= 0) return MV_ERR_INVALID_ARG;
-    if (rows == 0) return MV_OK;
     if (!mv::rows_vec_ok(x, stride_x) || !mv::rows_vec_ok(y, stride_y) || !mv::aligned16(w))
         return MV_ERR_INVALID_ARG;
     hipLaunchKernelGGL(mv::rmsnorm_kernel<false>, dim3(rows), dim3(mv::kNormThreads), 0,
@@ -105,8 +105,8 @@ int mv_rmsnorm(const void* x, const void* w, void* y, int rows, int n, int64_t s
 int mv_rmsnorm_residual(const void* x, const void* r, const void* w, void* y, void* res_out,
                         int rows, int n, int64_t stride_x, int64_t stride_r, int64_t stride_y,
                         int64_t stride_res, float eps, mv_stream_t stream) {
+    if (rows == 0 && n > 0) return MV_OK;
     if (!x || !r || !w || !y || !res_out || rows < 0 || n <= 0) return MV_ERR_INVALID_ARG;
-    if (rows == 0) return MV_OK;
     if (!mv::rows_vec_ok(x, stride_x) || !mv::rows_vec_ok(r, stride_r) ||
         !mv::rows_vec_ok(y, stride_y) || !mv::rows_vec_ok(res_out, stride_res) ||
         !mv::aligned16(w))

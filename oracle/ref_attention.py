@@ -13,8 +13,13 @@ core/layer/model_prefill.py:49-52:
     in fp32, and rounded to bf16; k (rotated) and v are written into the cache in place;
   * causal=True aligns the mask to the bottom right: query i sees keys 0..cache_seqlens[b]+i;
   * query head h reads kv head h // (Hq / Hkv);
-  * S = q.k^T in fp32, softmax in fp32 with scale 1/sqrt(D) by default, P rounded to bf16 for
-    P.V (fp32 accumulate) while the normaliser sums the unrounded P; output bf16.
+  * S = q.k^T in fp32, softmax in fp32 with scale 1/sqrt(D) by default, output bf16.
+    `p_bf16=True` (default) additionally rounds P to bf16 before P.V while the normaliser sums
+    the unrounded P - what the package's tensor-core kernels do internally (P is an MMA operand).
+    That rounding is an implementation detail, not part of the contract: its realisation depends
+    on the kernel's tile order, so two correct kernels differ by up to
+    2^-9 * sum_t p_t |v_t| per element.  `p_bf16=False` is the exact-softmax form used for the
+    tight kernel checks.
 """
 import math
 
@@ -33,7 +38,7 @@ def _rotate_neox(x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor) -> torch
 
 def flash_attn_with_kvcache_ref(q, k_cache, v_cache, k, v, rotary_cos=None, rotary_sin=None,
                                 cache_seqlens=None, block_table=None, softmax_scale=None,
-                                causal=True):
+                                causal=True, p_bf16=True, return_p_bound=False):
     """q: [B,Sq,Hq,D]; k, v: [B,Sq,Hkv,D]; caches mutated in place; returns [B,Sq,Hq,D] bf16."""
     B, Sq, Hq, D = q.shape
     Hkv = k.shape[2]
@@ -41,6 +46,7 @@ def flash_attn_with_kvcache_ref(q, k_cache, v_cache, k, v, rotary_cos=None, rota
     page = k_cache.shape[1]
     scale = softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D)
     out = torch.empty(B, Sq, Hq, D, dtype=BF16)
+    bound = torch.zeros(B, Sq, Hq, D) if return_p_bound else None
     for b in range(B):
         p0 = int(cache_seqlens[b])
         pos = torch.arange(p0, p0 + Sq)
@@ -71,6 +77,9 @@ def flash_attn_with_kvcache_ref(q, k_cache, v_cache, k, v, rotary_cos=None, rota
             m = s_.max(dim=-1, keepdim=True).values
             p = torch.exp(s_ - m)
             l = p.sum(dim=-1, keepdim=True)
-            o = (p.to(BF16).float() @ vh) / l
+            pv = p.to(BF16).float() if p_bf16 else p
+            o = (pv @ vh) / l
             out[b, :, h] = o.to(BF16)
-    return out
+            if return_p_bound:
+                bound[b, :, h] = (p @ vh.abs()) / l * 2.0 ** -9
+    return (out, bound) if return_p_bound else out

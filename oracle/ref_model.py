@@ -41,7 +41,12 @@ class RefShard:
 
 
 class RefRunner:
-    def __init__(self, model, head_size, world=1, max_blocks=32, fp32_weights=False):
+    def __init__(self, model, head_size, world=1, max_blocks=32, fp32_weights=False, p_bf16=False):
+        """p_bf16: round the softmax probabilities to bf16 before P.V, as the tensor-core kernels
+        of the flash-attn package do internally.  Off by default: an eager restatement of
+        attention is softmax(QK^T)V in fp32, and that internal rounding is not reproducible by
+        any other kernel (its realisation depends on the package's tile order)."""
+        self.p_bf16 = p_bf16
         cfg = model.config
         self.model, self.world, self.D = model, world, head_size
         self.hq = cfg.num_attention_heads // world          # core/engine.py:112
@@ -65,33 +70,50 @@ class RefRunner:
         v = qkv[..., (hq + hkv) * D:].reshape(*lead, hkv, D)
         return q, k, v
 
-    def decode(self, input_ids, caches, seqlens, block_table):
-        """model_graph.py:192-223.  caches[r] = (k_caches, v_caches) lists per layer for rank r;
-        seqlens int32 [bs]; block_table int32 [bs, max_blocks].  Returns logits [bs,V] bf16."""
+    def decode_layer(self, h, li, caches, seqlens, block_table):
+        """One block of model_graph.py:202-219 on hidden state h [bs, hid] bf16."""
+        block = self.model.transformer.h[li]
+        bs = h.shape[0]
+        normed = rmsnorm_ref(h, block.ln_1.weight, block.ln_1.eps)                 # :143
+        parts = []
+        for r, sh in enumerate(self.shards):
+            w = sh.layers[li]
+            qkv = linear_ref(normed, w["qkv"], w["qkv_b"])                         # :145-147
+            q, k, v = self._split_qkv(qkv, (bs,))
+            attn = flash_attn_with_kvcache_ref(                                    # :161-168
+                q.unsqueeze(1), caches[r][0][li], caches[r][1][li], k.unsqueeze(1),
+                v.unsqueeze(1), self.cos, self.sin, seqlens, block_table, causal=True,
+                p_bf16=self.p_bf16).squeeze(1)
+            parts.append(linear_ref(attn.reshape(bs, -1), w["o"]))                 # :171
+        attn_out = self._allreduce(parts)                                          # :210
+        normed, residual = rmsnorm_residual_ref(attn_out, h, block.ln_2.weight, block.ln_2.eps)  # :213
+        parts = []
+        for sh in self.shards:
+            w = sh.layers[li]
+            gu = linear_ref(normed, w["gu"])                                       # :183
+            parts.append(linear_ref(swiglu_ref(gu), w["d"]))                       # :184-185
+        return (self._allreduce(parts).float() + residual.float()).to(BF16)        # :219
+
+    def head(self, h, fp32=False):
+        """model_graph.py:222-223; fp32=True returns the logits before their bf16 rounding."""
         tr = self.model.transformer
-        bs = input_ids.shape[0]
-        h = tr.wte.weight[input_ids]                                               # :196
-        for li, block in enumerate(tr.h):
-            normed = rmsnorm_ref(h, block.ln_1.weight, block.ln_1.eps)             # :143
-            parts = []
-            for r, sh in enumerate(self.shards):
-                w = sh.layers[li]
-                qkv = linear_ref(normed, w["qkv"], w["qkv_b"])                     # :145-147
-                q, k, v = self._split_qkv(qkv, (bs,))
-                attn = flash_attn_with_kvcache_ref(                                # :161-168
-                    q.unsqueeze(1), caches[r][0][li], caches[r][1][li], k.unsqueeze(1),
-                    v.unsqueeze(1), self.cos, self.sin, seqlens, block_table, causal=True).squeeze(1)
-                parts.append(linear_ref(attn.reshape(bs, -1), w["o"]))             # :171
-            attn_out = self._allreduce(parts)                                      # :210
-            normed, residual = rmsnorm_residual_ref(attn_out, h, block.ln_2.weight, block.ln_2.eps)  # :213
-            parts = []
-            for sh in self.shards:
-                w = sh.layers[li]
-                gu = linear_ref(normed, w["gu"])                                   # :183
-                parts.append(linear_ref(swiglu_ref(gu), w["d"]))                   # :184-185
-            h = (self._allreduce(parts).float() + residual.float()).to(BF16)       # :219
-        h = rmsnorm_ref(h, tr.ln_f.weight, tr.ln_f.eps)                            # :222
-        return linear_ref(h, self.lm_head)                                         # :223
+        hn = rmsnorm_ref(h, tr.ln_f.weight, tr.ln_f.eps)
+        if fp32:
+            return hn.float() @ self.lm_head.float().t()
+        return linear_ref(hn, self.lm_head)
+
+    def decode(self, input_ids, caches, seqlens, block_table, trace=None):
+        """model_graph.py:192-223.  caches[r] = (k_caches, v_caches) lists per layer for rank r;
+        seqlens int32 [bs]; block_table int32 [bs, max_blocks].  Returns logits [bs,V] bf16.
+        `trace` (a list) receives the hidden state entering each layer and the final one."""
+        h = self.model.transformer.wte.weight[input_ids]                           # :196
+        for li in range(len(self.model.transformer.h)):
+            if trace is not None:
+                trace.append(h)
+            h = self.decode_layer(h, li, caches, seqlens, block_table)
+        if trace is not None:
+            trace.append(h)
+        return self.head(h)
 
     def prefill(self, input_ids, caches, block_table):
         """model_prefill.py:23-62: fixed-length batch [B,S], RoPE outside the attention call with
@@ -110,7 +132,7 @@ class RefRunner:
                 q, k = rope_prefill_ref(q, k, self.cos, self.sin)                  # :46
                 attn = flash_attn_with_kvcache_ref(                                # :49-52
                     q, caches[r][0][li], caches[r][1][li], k, v, None, None, zeros, block_table,
-                    causal=True)
+                    causal=True, p_bf16=self.p_bf16)
                 parts.append(linear_ref(attn.reshape(B, S, -1), w["o"]))           # :54
             out = self._allreduce(parts)
             normed, residual = rmsnorm_residual_ref(out, h, block.ln_2.weight, block.ln_2.eps)  # :55

@@ -41,9 +41,11 @@ def test_wgemm_vs_oracle(mv, m, n, k):
     assert (acc.cpu() - want32).abs().max().item() <= 1e-4 * max(1.0, want32.abs().max().item())
     y = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
     want = linear_ref(x, w)
-    assert ulp_diff(y, want).max() <= 1
+    # fp32 order noise (1e-4 of the output scale, felt only by sums that cancel to ~0) plus one
+    # bf16 unit in the last place for values that sit on a rounding boundary
+    assert_close_bf16(y, want, atol=1e-4 * max(1.0, float(want32.abs().max())), rtol=2 ** -7,
+                      what=f"wgemm m={m} n={n} k={k}")
     assert float((ulp_diff(y, want) == 0).float().mean()) > 0.99
-    assert_close_bf16(y, want, what=f"wgemm m={m} n={n} k={k}")
 
 
 @pytest.mark.parametrize("m", [1, 4, 6, 32])
@@ -101,12 +103,12 @@ def test_wgemm_ksplit_variants_agree_and_are_deterministic(mv):
             y1 = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
             y2 = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
             assert torch.equal(y1, y2), f"ksplit {ks}: run-to-run difference"
-            assert ulp_diff(y1, want).max() <= 1
+            assert_close_bf16(y1, want, atol=1e-3, rtol=2 ** -7)
             outs.append(y1)
         for bpc in (1, 2, 4):
             assert nv.lib().mv_wgemm_tune(0, bpc) == 0
             y = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
-            assert ulp_diff(y, want).max() <= 1
+            assert_close_bf16(y, want, atol=1e-3, rtol=2 ** -7)
     finally:
         nv.lib().mv_wgemm_tune(1, 0)
         nv.lib().mv_wgemm_tune(0, 2)
