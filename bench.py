@@ -1,0 +1,362 @@
+"""Decode-path benchmark: tokens/s of paged-KV single-token decode on a random-weight
+Llama-shaped model, with the HBM roofline of the dominant kernel and the CPU restatement of
+the reference path timed beside it.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1: one process)
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (tensor parallel)
+
+A step = one token for every sequence of the batch: KVCacheManager.append + cache_batch_data
+(host), hipGraph replay of the whole N-layer forward (device), greedy argmax on the device
+feeding the next step.  Inputs (weights, KV pages, block tables) are resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import math
+import os
+import random
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, vendor peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--model", default="llama3-8b")
+    ap.add_argument("--bs", type=int, default=1)
+    ap.add_argument("--ctx", type=int, default=4096)
+    ap.add_argument("--layers", type=int, default=0, help="build only this many layers (debug)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="per-projection GB/s table on stderr")
+    return ap.parse_args()
+
+
+def build(args, dev, world):
+    import micro_vllm_amd  # noqa: F401
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+    from micro_vllm_amd.core.layer.model_graph import ModelGraphRunner
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES[args.model]
+    layers = args.layers or cfg.num_hidden_layers
+    model = build_synthetic_model(cfg, dev, seed=1234, num_layers=layers)
+    total_tokens = args.ctx + args.steps + args.warmup + 8
+    blocks_per_seq = (total_tokens + 255) // 256 + 1
+    runner = ModelGraphRunner(
+        model, layers, cfg.num_attention_heads // world, cfg.head_dim,
+        cfg.num_key_value_heads // world, cfg.hidden_size, cfg.intermediate_size // world, dev,
+        max_batch_size=args.bs, max_blocks=max(32, blocks_per_seq), release_source_weights=True)
+    mgr = KVCacheManager(args.bs * blocks_per_seq + 2, 256, layers, cfg.num_key_value_heads // world,
+                         cfg.head_dim, dtype=torch.bfloat16, device=dev,
+                         max_tokens=blocks_per_seq * 256, max_batch_size=args.bs)
+    # non-contiguous pages (seed 2) and N(0,1) KV contents (seed 1): pure-bandwidth timing
+    order = list(mgr._free)
+    random.Random(2).shuffle(order)
+    mgr._free.clear()
+    mgr._free.extend(order)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    mgr._k_store.normal_(0.0, 1.0, generator=g)
+    mgr._v_store.normal_(0.0, 1.0, generator=g)
+    for sid in range(args.bs):
+        ok, _ = mgr.alloc(sid, args.ctx)
+        assert ok, "KV pool too small"
+    return cfg, layers, runner, mgr
+
+
+def gemm_only_timing(runner, bs, layers, reps=20):
+    """Average duration of the projection kernels of one decode step, launched back to back
+    (hipGraph of exactly those launches) and bracketed by HIP events on the launch stream."""
+    import ctypes
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.kernel.linear import wgemm
+
+    tr = runner.model.transformer
+
+    def one_pass():
+        for li in range(layers):
+            b = tr.h[li]
+            wgemm(runner._normed[:bs], b.attn._qkv_w, runner._qkv[:bs], bias=b.attn._qkv_b,
+                  workspace=runner._gemm_ws)
+            wgemm(runner._attn[:bs].reshape(bs, -1), b.attn._o, runner._attn_out[:bs],
+                  workspace=runner._gemm_ws)
+            wgemm(runner._normed[:bs], b.mlp._gu, runner._swiglu_out[:bs], swiglu=True,
+                  workspace=runner._gemm_ws)
+            wgemm(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs],
+                  residual=runner._residual[:bs], workspace=runner._gemm_ws)
+        wgemm(runner._normed[:bs], runner._lm_head, runner._logits[:bs], workspace=runner._gemm_ws)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        one_pass()
+        side.synchronize()
+        nv.check("begin", nv.lib().mv_graph_begin_capture(side.cuda_stream))
+        one_pass()
+        h = ctypes.c_void_p()
+        nv.check("end", nv.lib().mv_graph_end_capture(side.cuda_stream, ctypes.byref(h)))
+        for _ in range(3):
+            nv.lib().mv_graph_launch(h, side.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for _ in range(reps):
+            nv.lib().mv_graph_launch(h, side.cuda_stream)
+        e1.record(side)
+        side.synchronize()
+        nv.lib().mv_graph_destroy(h)
+    torch.cuda.current_stream().wait_stream(side)
+    n_launch = 4 * layers + 1
+    return e0.elapsed_time(e1) * 1e-3 / (reps * n_launch), n_launch
+
+
+def shape_table(runner, bs, layers):
+    """Per-projection streaming rate, cycling over the layers' distinct weights (no cache reuse)."""
+    from micro_vllm_amd.kernel.linear import wgemm
+
+    tr = runner.model.transformer
+    rows = []
+    specs = [
+        ("qkv", lambda b: wgemm(runner._normed[:bs], b.attn._qkv_w, runner._qkv[:bs], workspace=runner._gemm_ws), lambda b: b.attn._qkv_w),
+        ("o", lambda b: wgemm(runner._attn[:bs].reshape(bs, -1), b.attn._o, runner._attn_out[:bs], workspace=runner._gemm_ws), lambda b: b.attn._o),
+        ("gate_up+swiglu", lambda b: wgemm(runner._normed[:bs], b.mlp._gu, runner._swiglu_out[:bs], swiglu=True, workspace=runner._gemm_ws), lambda b: b.mlp._gu),
+        ("down", lambda b: wgemm(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs], workspace=runner._gemm_ws), lambda b: b.mlp._d),
+    ]
+    for name, fn, wof in specs:
+        for li in range(layers):
+            fn(tr.h[li])
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 5
+        for _ in range(reps):
+            for li in range(layers):
+                fn(tr.h[li])
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e-3 / (reps * layers)
+        nbytes = wof(tr.h[0]).nbytes
+        rows.append((name, nbytes, t))
+        log(f"[shapes] {name:16s} {nbytes/1e6:8.1f} MB  {t*1e6:8.2f} us  {nbytes/t/1e9:8.1f} GB/s (eager launches, incl. gaps)")
+    return rows
+
+
+def cpu_baseline(args, cfg, runner, dev):
+    """The CPU restatement of the reference's decode path (oracle/ref_model.py) on the host cores:
+    2 transformer layers + final norm + LM head of the same random model at the same context,
+    median step time, extrapolated to the full depth."""
+    from micro_vllm_amd.models.synthetic import SyntheticModel, _Attn, _Block, _Mlp, _Param, _Transformer
+    from micro_vllm_amd.models import build_synthetic_model
+    from oracle.ref_cache import RefKVCache
+    from oracle.ref_model import RefRunner
+    import dataclasses
+
+    n_sample = 2
+    torch.set_num_threads(os.cpu_count() or 1)
+    cores = torch.get_num_threads()
+    # same generator recipe as the device model, CPU side, sample layers only (seeded; the values
+    # differ from the device model's, the shapes and work do not)
+    small_vocab_cfg = cfg
+    model = build_synthetic_model(small_vocab_cfg, "cpu", seed=1234, num_layers=n_sample)
+    ref = RefRunner(model, cfg.head_dim, world=1, max_blocks=max(32, (args.ctx + 300) // 256 + 1),
+                    fp32_weights=True)
+    pages = (args.ctx + 2 + 255) // 256 + 1
+    cache = RefKVCache(args.bs * pages + 1, 256, n_sample, cfg.num_key_value_heads, cfg.head_dim,
+                       max_tokens=pages * 256, max_batch_size=args.bs, strict_reference=False)
+    g = torch.Generator().manual_seed(1)
+    for li in range(n_sample):
+        cache.k_caches[li].normal_(0.0, 1.0, generator=g)
+        cache.v_caches[li].normal_(0.0, 1.0, generator=g)
+    for sid in range(args.bs):
+        cache.alloc(sid, args.ctx)
+    ids = torch.randint(0, cfg.vocab_size, (args.bs,), generator=torch.Generator().manual_seed(0))
+    pos = args.ctx + 1
+    t_layers, t_head = [], []
+    for it in range(2 + 5):
+        for sid in range(args.bs):
+            cache.append(sid)
+        bt, sl = cache.cache_batch_data(list(range(args.bs)), [pos] * args.bs)
+        t0 = time.perf_counter()
+        h = model.transformer.wte.weight[ids]
+        for li in range(n_sample):
+            h = ref.decode_layer(h, li, [(cache.k_caches, cache.v_caches)], sl, bt)
+        t1 = time.perf_counter()
+        ref.head(h)
+        t2 = time.perf_counter()
+        if it >= 2:
+            t_layers.append((t1 - t0) / n_sample)
+            t_head.append(t2 - t1)
+        pos += 1
+    step = statistics.median(t_layers) * cfg.num_hidden_layers + statistics.median(t_head)
+    return {
+        "value": round(args.bs / step, 4),
+        "unit": "tokens/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"CPU restatement of the reference decode path (oracle/ref_model.py, fp32 math on "
+                   f"bf16-valued weights): {n_sample} of {cfg.num_hidden_layers} layers + LM head at "
+                   f"ctx {args.ctx}, bs {args.bs}, median of 5 steps after 2 warm-up; per-layer time "
+                   f"x{cfg.num_hidden_layers} + head = {step*1e3:.0f} ms/step"),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        log(f"--gpus {args.gpus} needs the torch.distributed.run launcher; running 1 GPU")
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+
+    import micro_vllm_amd  # noqa: F401
+    from micro_vllm_amd.core import parallel_config as pc
+    from micro_vllm_amd.core.layer.sampler import greedy
+
+    pc.setup()
+    t_build = time.time()
+    cfg, layers, runner, mgr = build(args, dev, world)
+    bs = args.bs
+    if not args.no_graph:
+        runner.capture(mgr, batch_sizes=[bs])
+    torch.cuda.synchronize()
+    log(f"[bench] rank {rank}/{world}: {cfg.name} x{layers} layers built + captured in {time.time()-t_build:.1f}s")
+
+    seq_ids = list(range(bs))
+    ids = torch.randint(0, cfg.vocab_size, (bs,), generator=torch.Generator().manual_seed(0)).to(dev)
+    next_ids = torch.zeros(bs, dtype=torch.long, device=dev)
+    pos = args.ctx + 1  # the engine's first decode position after a ctx-token prompt
+
+    def step(ids, pos):
+        for sid in seq_ids:
+            mgr.append(sid)
+        mgr.cache_batch_data(seq_ids, [pos] * bs)
+        logits = runner.forward(ids, mgr, bs)
+        return greedy(logits, out=next_ids)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ids = step(ids, pos)
+        pos += 1
+    sync_all()
+    pos0 = pos
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids = step(ids, pos)
+        pos += 1
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(runner._logits[:bs].float()).all()), "non-finite logits"
+
+    ms_per_step = dt / args.steps * 1e3
+    tok_s = bs * args.steps / dt
+
+    # ---- algorithmic bytes of one step on one GPU ---------------------------------------
+    full_cfg_bytes = cfg.weight_bytes(world)
+    if layers != cfg.num_hidden_layers:  # debug slices: count what was built
+        import dataclasses
+        full_cfg_bytes = dataclasses.replace(cfg, num_hidden_layers=layers).weight_bytes(world)
+    kv_tok = cfg.kv_bytes_per_token(world) * layers // cfg.num_hidden_layers
+    mean_keys = (pos0 + pos - 1) / 2.0 + 1.0
+    kv_bytes = bs * (mean_keys + 1.0) * kv_tok
+    step_bytes = full_cfg_bytes + kv_bytes
+    step_gbs = step_bytes / (dt / args.steps) / 1e9
+
+    out = {
+        "metric": "decode tokens/sec (paged-KV single-token decode, whole job)",
+        "value": round(tok_s, 2),
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"{cfg.name}-shaped random weights, TP={world} bf16, bs={bs}, "
+                         f"seq_len={args.ctx} paged decode (page 256, shuffled block table)"),
+            "global_batch": bs,
+            "seq_len": args.ctx,
+            "layers": layers,
+            "parallelism": f"tp{world}",
+            "graph": not args.no_graph,
+            "sampling": "greedy argmax on device",
+        },
+        "step_algorithmic_GB": round(step_bytes / 1e9, 3),
+        "step_GBps": round(step_gbs, 1),
+        "step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
+    }
+
+    if rank == 0:
+        try:
+            t_k, n_launch = gemm_only_timing(runner, bs, layers)
+            per_launch = full_cfg_bytes / n_launch
+            ach = per_launch / t_k / 1e9
+            kname = "wgemm_dot_kernel" if bs <= 4 else "wgemm_mfma_kernel"
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get(f"{kname}:{cfg.name}:bs{bs}:tp{world}")
+                except Exception:
+                    traffic = None
+            out["roofline"] = {
+                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": kname,
+                "bytes_per_launch": int(per_launch),
+                "avg_launch_us": round(t_k * 1e6, 3),
+                "launches_per_step": n_launch,
+            }
+        except Exception as e:  # the headline number must still be printed
+            log(f"[bench] roofline measurement failed: {e!r}")
+            out["roofline"] = None
+        if args.shapes:
+            shape_table(runner, bs, layers)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, cfg, runner, dev)
+            except Exception as e:
+                log(f"[bench] cpu baseline failed: {e!r}")
+                out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -145,6 +145,13 @@ int mv_store_kv(const void* key, const void* value, int64_t kv_stride_t, void* k
                 void* v_cache, const int32_t* slot_mapping, int tokens, int heads, int d,
                 int page, int num_pages, mv_stream_t stream);
 
+/* ------------------------------------------------------------- sampling */
+
+/* ids[r] = argmax_c logits[r, c] over bf16 logits [rows, n] (row stride ld), lowest index on
+ * ties; ids are int64.  The greedy (temperature -> 0) case of core/layer/sampler.py:21-43,
+ * done on the device so the step needs no [bs,V] sort and no host round trip. */
+int mv_argmax(const void* logits, int64_t ld, int rows, int n, int64_t* ids, mv_stream_t stream);
+
 /* ------------------------------------------------------------ hipGraph */
 
 /* Capture everything launched on `stream` between begin and end into an

@@ -73,11 +73,19 @@ class KVCacheManager:
         self._block_table_buffer = torch.full((max_batch_size, self.max_seq_blocks), -1,
                                               dtype=torch.int32, device=device)
         self._cache_seqlens_buffer = torch.zeros(max_batch_size, dtype=torch.int32, device=device)
-        # host staging for the per-step rewrite (one copy each instead of one per row)
-        pin = torch.cuda.is_available() and str(device).startswith("cuda")
-        self._bt_host = torch.full((max_batch_size, self.max_seq_blocks), -1, dtype=torch.int32,
-                                   pin_memory=pin)
-        self._sl_host = torch.zeros(max_batch_size, dtype=torch.int32, pin_memory=pin)
+        # Pinned host staging for the per-step rewrite: one asynchronous copy per buffer instead
+        # of one per row.  The copies are stream-ordered behind earlier decode steps, so the host
+        # may be several steps ahead of the device; a small ring of staging buffers, each guarded
+        # by an event recorded after its copy, keeps the host from overwriting bytes a queued
+        # copy has not read yet.
+        self._on_gpu = torch.cuda.is_available() and str(device).startswith("cuda")
+        self._ring = 4 if self._on_gpu else 1
+        self._bt_host = [torch.full((max_batch_size, self.max_seq_blocks), -1, dtype=torch.int32,
+                                    pin_memory=self._on_gpu) for _ in range(self._ring)]
+        self._sl_host = [torch.zeros(max_batch_size, dtype=torch.int32, pin_memory=self._on_gpu)
+                         for _ in range(self._ring)]
+        self._ring_events = [None] * self._ring
+        self._ring_next = 0
 
     # ------------------------------------------------------------------ allocation
     def alloc(self, seq_id: int, n_tokens: int):
@@ -138,7 +146,11 @@ class KVCacheManager:
         """Rewrite rows [0, len(seq_ids)) of the static block table / seqlens buffers in place."""
         n = len(seq_ids)
         if n > 0:
-            bt = self._bt_host
+            slot = self._ring_next
+            self._ring_next = (slot + 1) % self._ring
+            if self._ring_events[slot] is not None:
+                self._ring_events[slot].synchronize()
+            bt, sl = self._bt_host[slot], self._sl_host[slot]
             bt[:n].fill_(-1)
             for i, sid in enumerate(seq_ids):
                 blocks = self._blocks.get(sid, [])
@@ -148,9 +160,13 @@ class KVCacheManager:
                             f"sequence {sid} spans {len(blocks)} blocks but the block table is "
                             f"{self.max_seq_blocks} wide (max_tokens={self.max_tokens})")
                     bt[i, :len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
-            self._sl_host[:n] = torch.tensor(context_lens, dtype=torch.int32)
+            sl[:n] = torch.tensor(context_lens, dtype=torch.int32)
             self._block_table_buffer[:n].copy_(bt[:n], non_blocking=True)
-            self._cache_seqlens_buffer[:n].copy_(self._sl_host[:n], non_blocking=True)
+            self._cache_seqlens_buffer[:n].copy_(sl[:n], non_blocking=True)
+            if self._on_gpu:
+                ev = self._ring_events[slot] or torch.cuda.Event()
+                ev.record()
+                self._ring_events[slot] = ev
         return self._block_table_buffer[:n], self._cache_seqlens_buffer[:n]
 
     def get_buffer_data(self, seq_ids: list):
