@@ -104,6 +104,22 @@ int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
              const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n, int k,
              void* workspace, size_t workspace_bytes, int flags, mv_stream_t stream);
 
+/* mv_wgemm with the input transform of the preceding norm kernel folded in (1 <= M <= 4):
+ *   add_r == NULL:  x' = rmsnorm(x) * ln_w                       (mv_rmsnorm, then mv_wgemm)
+ *   add_r != NULL:  s = x + add_r; sum_out = bf16(s); x' = rmsnorm(s) * ln_w
+ *                                                    (mv_rmsnorm_residual, then mv_wgemm)
+ * with exactly the rounding of those two-kernel sequences (results are bit-identical to them).
+ * norm_flags & MV_NORM_VAR_FROM_ROUNDED takes the variance from bf16(s) instead of the fp32 s:
+ * that is `h = a.add_(r)` followed by rmsnorm_(h) (core/layer/model_graph.py:219 then :143).
+ * Replaces rmsnorm_ + matmul (model_graph.py:143-145), rmsnorm_residual_gemm + matmul
+ * (:213, :183) and ln_f + lm_head (:222-223) as single launches. */
+enum { MV_NORM_VAR_FROM_ROUNDED = 1 };
+int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_r,
+                  const void* ln_w, float eps, void* sum_out, int64_t ld_sum_out, int norm_flags,
+                  const void* w_tiles, const void* bias, const void* residual, int64_t ld_res,
+                  void* y, int64_t ldy, int m, int n, int k, void* workspace,
+                  size_t workspace_bytes, int flags, mv_stream_t stream);
+
 /* Launch-shape knobs for experiments (no counterpart in the reference):
  * key 0 = workgroups per CU the grid is sized for (1..8, default 2);
  * key 1 = forced number of k-slices per strip (0 = pick automatically). */
@@ -117,6 +133,11 @@ size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_split
 /* How many KV splits the library would pick for this shape (ctx_hint = typical
  * context length; <= 0 means unknown). */
 int mv_paged_attn_decode_pick_splits(int bs, int hkv, int ctx_hint);
+
+/* Experiment knobs (no counterpart in the reference): key 0 = merge the KV splits inside the
+ * attention kernel (1, default) or in a second launch (0); key 1 = workgroups per CU the
+ * automatic split count aims at (default 2). */
+int mv_paged_attn_tune(int key, int value);
 
 /* Single-token paged attention with in-kernel NeoX RoPE and KV append.
  * For each row b with p = cache_seqlens[b]:

@@ -20,6 +20,7 @@ MV_ERR_GRAPH = -5
 MV_GEMM_DEFAULT = 0
 MV_GEMM_SWIGLU = 1
 MV_GEMM_OUT_F32 = 2
+MV_NORM_VAR_FROM_ROUNDED = 1
 
 _P = c_void_p
 _I = c_int
@@ -42,8 +43,11 @@ PROTOTYPES = {
     "mv_wgemm_workspace_bytes": (_Z, [_I, _I, _I]),
     "mv_wgemm_tune": (_I, [_I, _I]),
     "mv_wgemm": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P, _Z, _I, _P]),
+    "mv_wgemm_norm": (_I, [_P, _L, _P, _L, _P, _F, _P, _L, _I, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P,
+                           _Z, _I, _P]),
     "mv_paged_attn_decode_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "mv_paged_attn_decode_pick_splits": (_I, [_I, _I, _I]),
+    "mv_paged_attn_tune": (_I, [_I, _I]),
     "mv_paged_attn_decode": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _Z,
                                   _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mv_store_kv": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

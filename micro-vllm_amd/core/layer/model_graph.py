@@ -9,8 +9,10 @@ Differences that are deliberate:
     `reshape(bs, 3, H, D)` when Hkv == Hq and also covers grouped-query shapes;
   * the eager (uncaptured) path uses the real block table, not the all-zero one of
     model_graph.py:155-159;
-  * `fused=True` (default) folds bias, SwiGLU and the final residual add into GEMM epilogues;
-    every rounding still happens where the reference's separate ops round.
+  * `fused=True` (default) folds bias, SwiGLU and the final residual add into GEMM epilogues
+    and, for batches of up to 4 rows, the two norms into the prologue of the GEMM that consumes
+    them (5 launches per layer instead of 9); every rounding still happens where the
+    reference's separate ops round, and the fused and unfused paths agree bit for bit.
 """
 import logging
 from typing import Dict, List
@@ -20,7 +22,7 @@ import torch
 from .. import parallel_config as pc
 from ..paged_attention import PagedAttention, paged_attn_decode
 from ... import _native as nv
-from ...kernel.linear import StreamedWeight, add_, embedding, gemm_workspace, wgemm
+from ...kernel.linear import StreamedWeight, add_, embedding, gemm_workspace, wgemm, wgemm_norm
 from ...kernel.rmsnorm_add import rmsnorm_
 from ...kernel.rmsnorm_residual import rmsnorm_residual_gemm
 from ...kernel.swiglu import swiglu_gemm
@@ -145,6 +147,7 @@ class ModelGraphRunner:
         self._gate_up = torch.empty((max_b, self.intermediate_size), dtype=dt, device=dev)
         self._swiglu_out = torch.empty((max_b, self.intermediate_size // 2), dtype=dt, device=dev)
         self._mlp_out = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
+        self._hsum = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
         # split-k slabs of the widest projection and split-KV partials: sized once, never regrown
         L = nv.lib()
         need = 0
@@ -209,6 +212,9 @@ class ModelGraphRunner:
     def _layer(self, h, layer_idx, bs, cache_manager):
         """One transformer block on hidden state `h` [bs, hid]; returns the next hidden state
         (a view of a static buffer)."""
+        if self.fused and bs <= 4:
+            out, pend = self._layer_norm_fused(h, None, layer_idx, bs, cache_manager)
+            return out if pend is None else add_(out, pend)
         block = self.model.transformer.h[layer_idx]
         qkv = self._qkv_proj(h, block, bs)
         attn_out = self._flash_attn(qkv, block, layer_idx, bs, cache_manager)
@@ -220,17 +226,58 @@ class ModelGraphRunner:
         mlp_out = self._ffn(self._normed[:bs], block, bs)
         return add_(pc.all_reduce(mlp_out), self._residual[:bs])
 
-    def _head(self, h, bs, out=None):
+    def _layer_norm_fused(self, h, pend, layer_idx, bs, cache_manager):
+        """Block with both norms folded into the consuming projections (bs <= 4).
+
+        `pend` is a residual that still has to be added to `h` (tensor-parallel runs: the sum
+        `all_reduce(mlp_out) + residual` of the previous block is formed in this block's QKV
+        prologue).  Returns (out, pend_out) with the same meaning for the next block."""
+        block = self.model.transformer.h[layer_idx]
+        ws = self._gemm_ws
+        if pend is None:
+            wgemm_norm(h, block.ln_1.weight, block.ln_1.eps, block.attn._qkv_w, self._qkv[:bs],
+                       bias=block.attn._qkv_b, workspace=ws)
+        else:
+            # h <- bf16(h + pend) (model_graph.py:219), then rmsnorm_ of the ROUNDED sum (:143)
+            wgemm_norm(h, block.ln_1.weight, block.ln_1.eps, block.attn._qkv_w, self._qkv[:bs],
+                       add_r=pend, sum_out=self._hsum[:bs], var_from_rounded=True,
+                       bias=block.attn._qkv_b, workspace=ws)
+            h = self._hsum[:bs]
+        attn_out = self._flash_attn(self._qkv[:bs], block, layer_idx, bs, cache_manager)
+        attn_out = pc.all_reduce(attn_out)
+        wgemm_norm(attn_out, block.ln_2.weight, block.ln_2.eps, block.mlp._gu, self._swiglu_out[:bs],
+                   add_r=h, sum_out=self._residual[:bs], swiglu=True, workspace=ws)
+        if self.world_size == 1:
+            wgemm(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs],
+                  residual=self._residual[:bs], workspace=ws)
+            return self._mlp_out[:bs], None
+        wgemm(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs], workspace=ws)
+        return pc.all_reduce(self._mlp_out[:bs]), self._residual[:bs]
+
+    def _head(self, h, bs, out=None, pend=None):
         """Final norm + LM head; `out` may be an fp32 [bs,V] tensor to get un-rounded logits."""
         tr = self.model.transformer
+        dst = self._logits[:bs] if out is None else out
+        if self.fused and bs <= 4:
+            if pend is None:
+                return wgemm_norm(h, tr.ln_f.weight, tr.ln_f.eps, self._lm_head, dst,
+                                  workspace=self._gemm_ws)
+            return wgemm_norm(h, tr.ln_f.weight, tr.ln_f.eps, self._lm_head, dst, add_r=pend,
+                              sum_out=self._hsum[:bs], var_from_rounded=True, workspace=self._gemm_ws)
+        if pend is not None:
+            h = add_(h, pend)
         rmsnorm_(h, tr.ln_f.weight, self._normed[:bs], tr.ln_f.eps)
-        return wgemm(self._normed[:bs], self._lm_head, self._logits[:bs] if out is None else out,
-                     workspace=self._gemm_ws)
+        return wgemm(self._normed[:bs], self._lm_head, dst, workspace=self._gemm_ws)
 
     def decode(self, input_ids, bs, cache_manager, use_graph_cache=True):
         """One token for each of `bs` rows; returns logits [bs, V] (a view of a static buffer).
         Allocation-free after the first call for a given bs, so it can be stream-captured."""
         h = embedding(self.model.transformer.wte.weight, input_ids, self._hidden0[:bs])
+        if self.fused and bs <= 4:
+            pend = None
+            for layer_idx in range(self.num_layers):
+                h, pend = self._layer_norm_fused(h, pend, layer_idx, bs, cache_manager)
+            return self._head(h, bs, pend=pend)
         for layer_idx in range(self.num_layers):
             h = self._layer(h, layer_idx, bs, cache_manager)
         return self._head(h, bs)

@@ -9,8 +9,10 @@
 // Work split: workgroup = (sequence b, kv head, kv split); its 4 waves interleave
 // over the split's rows.  Every 16-lane (D=128) / 8-lane (D=64) row group keeps
 // its own online-softmax state (m, l, acc[G][8]); states meet once in LDS at the
-// end.  Splits write normalised fp32 partials + log2-sum-exp; a second small kernel
-// merges them (skipped when num_splits == 1).
+// end.  Splits write normalised fp32 partials + log2-sum-exp with write-through stores
+// and take a ticket on a per-(b, kv head) arrival counter; the workgroup that draws the
+// last ticket merges the partials in split order (deterministic) and writes the bf16
+// output, so no second launch is needed.  num_splits == 1 writes the output directly.
 //
 // Numerics: q and k are rotated in fp32 and rounded to bf16 (k is stored rotated);
 // scores, softmax, P and the P.V accumulation are all fp32.  (A tensor-core kernel
@@ -42,6 +44,7 @@ struct AttnArgs {
     uint16_t* out;
     float* part_lse;  // [bs*Hq*nsplit]
     float* part_o;    // [bs*Hq*nsplit*D]
+    unsigned int* arrive;  // [bs*Hkv] arrival counters (zero between launches); null = merge in a second kernel
     int bs, hq, hkv;
     int page, page_shift, num_pages;
     float scale_log2;
@@ -299,11 +302,80 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
         if (a.nsplit == 1) {
             a.out[((int64_t)b * a.hq + hq) * D + d] = (uint16_t)f32_to_bf16_bits(val);
         } else {
+            // write-through (sc1) stores: visible to the merging workgroup without a release fence
             const int64_t pi = ((int64_t)b * a.hq + hq) * a.nsplit + split;
-            a.part_o[pi * D + d] = val;
-            if (d == 0) a.part_lse[pi] = lt > 0.f ? mx + __builtin_amdgcn_logf(lt) : kNegBig;
+            __hip_atomic_store(reinterpret_cast<unsigned int*>(a.part_o + pi * D + d),
+                               __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned int*>(a.part_lse + pi),
+                                   __float_as_uint(lt > 0.f ? mx + __builtin_amdgcn_logf(lt) : kNegBig),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    if (a.nsplit == 1 || a.arrive == nullptr) return;
+
+    // ---- last-arriving split of this (b, kv head) merges all splits ---------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(lds);          // the state arrays are dead past the barrier
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(a.arrive + bh, 1u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+        *flag = (old == (unsigned)a.nsplit - 1u);
+    }
+    __syncthreads();
+    if (!*flag) return;
+    __syncthreads();  // everyone has read the flag before LDS is reused
+    // every load of handed-off data below is an sc1 (L1-bypassing) load
+    float* wts = lds;  // [G][nsplit] weights 2^(lse - max), then normalised
+    const int ns = a.nsplit;
+    for (int i = threadIdx.x; i < G * ns; i += kAT) {
+        const int g = i / ns, sp = i - g * ns;
+        const int64_t pi = ((int64_t)b * a.hq + kvh * G + g) * ns + sp;
+        wts[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(a.part_lse + pi),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        float* w = wts + threadIdx.x * ns;
+        float mx = kNegBig;
+        for (int sp = 0; sp < ns; ++sp) mx = fmaxf(mx, w[sp]);
+        float sum = 0.f;
+        for (int sp = 0; sp < ns; ++sp) {
+            w[sp] = __builtin_amdgcn_exp2f(w[sp] - mx);
+            sum += w[sp];
+        }
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        for (int sp = 0; sp < ns; ++sp) w[sp] *= inv;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < G * D; o += kAT) {
+        const int g = o / D, d = o - g * D;
+        const int hq = kvh * G + g;
+        const unsigned int* src =
+            reinterpret_cast<const unsigned int*>(a.part_o + (((int64_t)b * a.hq + hq) * ns) * D + d);
+        const float* w = wts + g * ns;
+        float acc_o = 0.f;
+        int sp = 0;
+        for (; sp + 8 <= ns; sp += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                v[j] = __uint_as_float(__hip_atomic_load(const_cast<unsigned int*>(src + (int64_t)(sp + j) * D),
+                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc_o = __builtin_fmaf(w[sp + j], v[j], acc_o);
+        }
+        for (; sp < ns; ++sp)
+            acc_o = __builtin_fmaf(
+                w[sp],
+                __uint_as_float(__hip_atomic_load(const_cast<unsigned int*>(src + (int64_t)sp * D),
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)),
+                acc_o);
+        a.out[((int64_t)b * a.hq + hq) * D + d] = (uint16_t)f32_to_bf16_bits(acc_o);
+    }
+    if (threadIdx.x == 0)  // leave the counter at zero for the next launch
+        __hip_atomic_store(a.arrive + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out[b,h,:] = sum_s w_s o_s / sum_s w_s,  w_s = 2^(lse_s - max lse)
@@ -317,13 +389,31 @@ __global__ __launch_bounds__(D) void paged_attn_combine_kernel(const float* __re
     const float* lse = part_lse + bh * nsplit;
     float mx = kNegBig;
     for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, lse[s]);
-    float wsum = 0.f, o = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float w = __builtin_amdgcn_exp2f(lse[s] - mx);
-        wsum += w;
-        o = __builtin_fmaf(w, part_o[(bh * nsplit + s) * D + d], o);
+    float wsum = 0.f;
+    for (int s = 0; s < nsplit; ++s) wsum += __builtin_amdgcn_exp2f(lse[s] - mx);
+    const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+    float o = 0.f;  // same arithmetic and order as the in-kernel merge: results are identical
+    for (int s = 0; s < nsplit; ++s)
+        o = __builtin_fmaf(__builtin_amdgcn_exp2f(lse[s] - mx) * inv, part_o[(bh * nsplit + s) * D + d], o);
+    out[bh * D + d] = (uint16_t)f32_to_bf16_bits(o);
+}
+
+// Arrival counters of the in-kernel split merge.  Zero at load time and returned to zero by the
+// merging workgroup, so a launch needs no memset; calls that overlap on one GPU would share
+// them and must not (one decode stream per process is the model here).
+constexpr int kMaxArrive = 16384;
+static __device__ unsigned int g_arrive[kMaxArrive];
+
+static unsigned int* arrive_counters() {
+    static unsigned int* cached[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!cached[dev]) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_arrive)) != hipSuccess) return nullptr;
+        cached[dev] = (unsigned int*)p;
     }
-    out[bh * D + d] = (uint16_t)f32_to_bf16_bits(wsum > 0.f ? o / wsum : 0.f);
+    return cached[dev];
 }
 
 template <int D, int G>
@@ -343,7 +433,7 @@ static int launch_decode(const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((paged_attn_decode_kernel<D, G>), dim3(a.bs * a.hkv * a.nsplit), dim3(kAT),
                        lds, s, a);
     int rc = check_launch();
-    if (rc != MV_OK || a.nsplit == 1) return rc;
+    if (rc != MV_OK || a.nsplit == 1 || a.arrive != nullptr) return rc;
     hipLaunchKernelGGL((paged_attn_combine_kernel<D>), dim3(a.bs * a.hq), dim3(D), 0, s,
                        a.part_lse, a.part_o, a.out, a.nsplit);
     return check_launch();
@@ -361,6 +451,8 @@ static int dispatch_g(const AttnArgs& a, int g, hipStream_t s) {
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static int g_tune_inkernel_merge = 1;
+static int g_tune_target_blocks_x = 2;  // split count aims at this many workgroups per CU
 
 }  // namespace mv
 
@@ -374,7 +466,7 @@ size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_split
 
 int mv_paged_attn_decode_pick_splits(int bs, int hkv, int ctx_hint) {
     if (bs <= 0 || hkv <= 0) return 1;
-    const int target = 2 * mv::num_cus();
+    const int target = mv::g_tune_target_blocks_x * mv::num_cus();
     int ns = (target + bs * hkv - 1) / (bs * hkv);
     if (ctx_hint > 0) {
         const int cap = ctx_hint / 64 > 1 ? ctx_hint / 64 : 1;  // at least 64 rows per split
@@ -383,6 +475,20 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int ctx_hint) {
     if (ns > 128) ns = 128;
     if (ns < 1) ns = 1;
     return ns;
+}
+
+/* Experiment knobs: key 0 = merge splits inside the kernel (1) or in a second launch (0);
+ * key 1 = workgroups per CU the automatic split count aims at. */
+int mv_paged_attn_tune(int key, int value) {
+    if (key == 0 && (value == 0 || value == 1)) {
+        mv::g_tune_inkernel_merge = value;
+        return MV_OK;
+    }
+    if (key == 1 && value >= 1 && value <= 8) {
+        mv::g_tune_target_blocks_x = value;
+        return MV_OK;
+    }
+    return MV_ERR_INVALID_ARG;
 }
 
 int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, const void* v_new,
@@ -439,6 +545,8 @@ int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, c
         a.part_lse = (float*)workspace;
         a.part_o = (float*)((char*)workspace + align_up(rows * sizeof(float), 256));
     }
+    a.arrive = nullptr;
+    if (num_splits > 1 && g_tune_inkernel_merge && bs * hkv <= kMaxArrive) a.arrive = arrive_counters();
     const int g = hq / hkv;
     hipStream_t s = (hipStream_t)stream;
     return d == 128 ? dispatch_g<128>(a, g, s) : dispatch_g<64>(a, g, s);

@@ -33,6 +33,8 @@ constexpr int kMaxKsplit = 8;
 static int g_tune_bpc = 2;      // workgroups per CU the grid is sized for
 static int g_tune_ksplit = 0;   // 0 = heuristic
 
+enum { kProNone = 0, kProNorm = 1, kProAddNorm = 2 };
+
 struct GemmArgs {
     const uint16_t* x;
     int64_t ldx;
@@ -48,6 +50,15 @@ struct GemmArgs {
     int ksplit, ktps;  // k-slices, k-tiles per slice
     int nunits;
     int flags;
+    // fused input transform (dot form only): x <- rmsnorm(x [+ add_r]) * ln_w
+    int prologue;
+    int var_from_rounded;       // kProAddNorm: variance from bf16(x + add_r) instead of the fp32 sum
+    const uint16_t* add_r;
+    int64_t ld_add_r;
+    const uint16_t* ln_w;
+    float eps;
+    uint16_t* sum_out;          // kProAddNorm: bf16(x + add_r), written by workgroup 0
+    int64_t ld_sum_out;
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -67,6 +78,11 @@ __device__ __forceinline__ float epilogue_value(const GemmArgs& a, float acc, in
 }
 
 // ------------------------------------------------------------ M <= 4: dot form
+struct UnitCtx {
+    int nt, ks, kt0, ntile, nchunk, last;
+    const uint4* wbase;
+};
+
 template <int M>
 __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -79,62 +95,156 @@ __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
 
-    // stage x (previous kernel's output; L2 resident) while nothing else is pending
-    {
-        const int kvec = a.k >> 3;
+    auto setup = [&](int u) {
+        UnitCtx c;
+        c.nt = u / a.ksplit;
+        c.ks = u - c.nt * a.ksplit;
+        c.kt0 = c.ks * a.ktps;
+        const int kt1 = min(a.kt, c.kt0 + a.ktps);
+        c.ntile = (kt1 - c.kt0 - wid + kGW - 1) / kGW;  // tiles of this wave (may be <= 0)
+        c.nchunk = (c.ntile + kU - 1) / kU;
+        c.last = max(c.ntile - 1, 0);
+        c.wbase = a.w + ((int64_t)c.nt * a.kt + c.kt0 + wid) * 64 + lane;
+        return c;
+    };
+    auto load = [&](uint4(&buf)[kU], const UnitCtx& c, int chunk) {
+#pragma unroll
+        for (int i = 0; i < kU; ++i) {
+            const int t = min(chunk * kU + i, c.last);  // clamp: always a valid address
+            buf[i] = ld16_nt(c.wbase + (int64_t)t * (kGW * 64));
+        }
+    };
+    auto compute = [&](const uint4(&buf)[kU], const UnitCtx& c, int chunk, float(&acc)[M]) {
+#pragma unroll
+        for (int i = 0; i < kU; ++i) {
+            const int t = chunk * kU + i;
+            // byte offset of this lane's 8 x values; out-of-range tiles read zeros
+            const int xoff = (t < c.ntile) ? ((c.kt0 + wid + t * kGW) * 32 + q * 8) * 2 : -1;
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const int off = (xoff < 0) ? zero_off : m * a.k * 2 + xoff;
+                const uint4 xv = *reinterpret_cast<const uint4*>(smem + off);
+                acc[m] = dot2_bf16(buf[i].x, xv.x, acc[m]);
+                acc[m] = dot2_bf16(buf[i].y, xv.y, acc[m]);
+                acc[m] = dot2_bf16(buf[i].z, xv.z, acc[m]);
+                acc[m] = dot2_bf16(buf[i].w, xv.w, acc[m]);
+            }
+        }
+    };
+
+    // The weights do not depend on the previous kernel: get the first tiles moving before
+    // touching x, so their HBM latency overlaps the input transform below.
+    int u = blockIdx.x;
+    UnitCtx cur = setup(u);
+    uint4 bufA[kU], bufB[kU];
+    if (cur.nchunk > 0) load(bufA, cur, 0);
+
+    // ---- stage x into LDS, optionally as rmsnorm(x [+ add_r]) * ln_w ------------------
+    const int kvec = a.k >> 3;
+    if (a.prologue == kProNone) {
         for (int c = threadIdx.x; c < M * kvec; c += kGT) {
             const int m = c / kvec, cv = c - m * kvec;
             st16(xs + m * a.k + cv * 8, ld16(a.x + (int64_t)m * a.ldx + cv * 8));
         }
         if (threadIdx.x == 0) *reinterpret_cast<uint4*>(smem + zero_off) = make_uint4(0, 0, 0, 0);
+    } else {
+        // Same chunk assignment (256 threads, stride 256) and the same reduction order as the
+        // stand-alone norm kernels, so fused and unfused paths agree bit for bit.
+        constexpr int kPT = 256;
+        float ss[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) ss[m] = 0.f;
+        if (threadIdx.x < kPT) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const uint16_t* xr = a.x + (int64_t)m * a.ldx;
+                for (int c = threadIdx.x; c < kvec; c += kPT) {
+                    const uint4 xv = ld16(xr + c * 8);
+                    const uint32_t x4[4] = {xv.x, xv.y, xv.z, xv.w};
+                    if (a.prologue == kProAddNorm) {
+                        const uint4 rv = ld16(a.add_r + (int64_t)m * a.ld_add_r + c * 8);
+                        const uint32_t r4[4] = {rv.x, rv.y, rv.z, rv.w};
+                        uint32_t o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float s0 = bf16_lo(x4[j]) + bf16_lo(r4[j]);
+                            float s1 = bf16_hi(x4[j]) + bf16_hi(r4[j]);
+                            o[j] = pack_bf16x2(s0, s1);
+                            if (a.var_from_rounded) {
+                                s0 = bf16_lo(o[j]);
+                                s1 = bf16_hi(o[j]);
+                            }
+                            ss[m] += s0 * s0;
+                            ss[m] += s1 * s1;
+                        }
+                        const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+                        st16(xs + m * a.k + c * 8, ov);
+                        if (blockIdx.x == 0) st16(a.sum_out + (int64_t)m * a.ld_sum_out + c * 8, ov);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v0 = bf16_lo(x4[j]), v1 = bf16_hi(x4[j]);
+                            ss[m] += v0 * v0;
+                            ss[m] += v1 * v1;
+                        }
+                        st16(xs + m * a.k + c * 8, xv);
+                    }
+                }
+            }
+        }
+        if (threadIdx.x == 0) *reinterpret_cast<uint4*>(smem + zero_off) = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const float v = wave_sum(ss[m]);
+            if (lane == 0 && wid < kPT / 64) red[m * (kPT / 64) + wid] = v;
+        }
+        __syncthreads();
+        float rrms[M];
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < kPT / 64; ++i) t += red[m * (kPT / 64) + i];
+            rrms[m] = 1.0f / sqrtf(t / (float)a.k + a.eps);
+        }
+        if (threadIdx.x < kPT) {
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                for (int c = threadIdx.x; c < kvec; c += kPT) {
+                    uint4* px = reinterpret_cast<uint4*>(xs + m * a.k + c * 8);
+                    const uint4 sv = *px, wv = ld16(a.ln_w + c * 8);
+                    const uint32_t s4[4] = {sv.x, sv.y, sv.z, sv.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[j] = pack_bf16x2((bf16_lo(s4[j]) * rrms[m]) * bf16_lo(w4[j]),
+                                           (bf16_hi(s4[j]) * rrms[m]) * bf16_hi(w4[j]));
+                    *px = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
     }
     __syncthreads();
 
-    for (int u = blockIdx.x; u < a.nunits; u += gridDim.x) {
-        const int nt = u / a.ksplit, ks = u - nt * a.ksplit;
-        const int kt0 = ks * a.ktps;
-        const int kt1 = min(a.kt, kt0 + a.ktps);
-        const int ntile = (kt1 - kt0 - wid + kGW - 1) / kGW;  // tiles of this wave (may be <= 0)
-        const uint4* wbase = a.w + ((int64_t)nt * a.kt + kt0 + wid) * 64 + lane;
-        const int last = max(ntile - 1, 0);
-
+    for (;;) {
         float acc[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[m] = 0.f;
 
-        uint4 bufA[kU], bufB[kU];
-        auto load = [&](uint4(&buf)[kU], int c) {
-#pragma unroll
-            for (int i = 0; i < kU; ++i) {
-                const int t = min(c * kU + i, last);  // clamp: always a valid address
-                buf[i] = ld16_nt(wbase + (int64_t)t * (kGW * 64));
-            }
-        };
-        auto compute = [&](const uint4(&buf)[kU], int c) {
-#pragma unroll
-            for (int i = 0; i < kU; ++i) {
-                const int t = c * kU + i;
-                // byte offset of this lane's 8 x values; out-of-range tiles read zeros
-                const int xoff = (t < ntile) ? ((kt0 + wid + t * kGW) * 32 + q * 8) * 2 : -1;
-#pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const int off = (xoff < 0) ? zero_off : m * a.k * 2 + xoff;
-                    const uint4 xv = *reinterpret_cast<const uint4*>(smem + off);
-                    acc[m] = dot2_bf16(buf[i].x, xv.x, acc[m]);
-                    acc[m] = dot2_bf16(buf[i].y, xv.y, acc[m]);
-                    acc[m] = dot2_bf16(buf[i].z, xv.z, acc[m]);
-                    acc[m] = dot2_bf16(buf[i].w, xv.w, acc[m]);
-                }
-            }
-        };
+        for (int c = 0; c < cur.nchunk; c += 2) {  // chunk 0 is already in bufA
+            if (c + 1 < cur.nchunk) load(bufB, cur, c + 1);
+            compute(bufA, cur, c, acc);
+            if (c + 2 < cur.nchunk) load(bufA, cur, c + 2);
+            if (c + 1 < cur.nchunk) compute(bufB, cur, c + 1, acc);
+        }
 
-        const int nchunk = (ntile + kU - 1) / kU;
-        if (nchunk > 0) load(bufA, 0);
-        for (int c = 0; c < nchunk; c += 2) {
-            if (c + 1 < nchunk) load(bufB, c + 1);
-            compute(bufA, c);
-            if (c + 2 < nchunk) load(bufA, c + 2);
-            if (c + 1 < nchunk) compute(bufB, c + 1);
+        // next unit's first tiles go out before this unit's reduction
+        const int un = u + gridDim.x;
+        const bool more = un < a.nunits;
+        UnitCtx nxt = cur;
+        if (more) {
+            nxt = setup(un);
+            if (nxt.nchunk > 0) load(bufA, nxt, 0);
         }
 
         // lanes r, r+16, r+32, r+48 hold the four k-quarters of row r
@@ -153,9 +263,9 @@ __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < kGW; ++w8) s += red[(w8 * M + m) * 16 + rr];
-            const int n = nt * 16 + rr;
+            const int n = cur.nt * 16 + rr;
             if (a.ksplit > 1) {
-                a.partial[((int64_t)ks * a.m + m) * a.n + n] = s;
+                a.partial[((int64_t)cur.ks * a.m + m) * a.n + n] = s;
             } else if (a.flags & MV_GEMM_OUT_F32) {
                 reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n] = s;
             } else if (a.flags & MV_GEMM_SWIGLU) {
@@ -163,7 +273,7 @@ __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
                     float g = 0.f;
 #pragma unroll
                     for (int w8 = 0; w8 < kGW; ++w8) g += red[(w8 * M + m) * 16 + rr + 8];
-                    reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + nt * 8 + rr] =
+                    reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + cur.nt * 8 + rr] =
                         (uint16_t)f32_to_bf16_bits(silu_mul_rounded(g, s));
                 }
             } else {
@@ -171,7 +281,10 @@ __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
                     (uint16_t)f32_to_bf16_bits(epilogue_value(a, s, m, n));
             }
         }
+        if (!more) break;
         __syncthreads();
+        u = un;
+        cur = nxt;
     }
 }
 
@@ -360,35 +473,12 @@ static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
     return check_launch();
 }
 
-}  // namespace mv
-
-extern "C" {
-
-// Tuning hook for experiments: key 0 = workgroups per CU, key 1 = forced ksplit (0 = auto).
-int mv_wgemm_tune(int key, int value) {
-    if (key == 0 && value >= 1 && value <= 8) {
-        mv::g_tune_bpc = value;
-        return MV_OK;
-    }
-    if (key == 1 && value >= 0 && value <= mv::kMaxKsplit) {
-        mv::g_tune_ksplit = value;
-        return MV_OK;
-    }
-    return MV_ERR_INVALID_ARG;
-}
-
-size_t mv_wgemm_workspace_bytes(int m, int n, int k) {
-    if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
-    // slabs for the split the planner picks now; a call that later finds the
-    // workspace too small (tuning changed) runs unsplit instead of failing
-    const int ks = mv::pick_ksplit(n / 16, k / 32);
-    return ks > 1 ? (size_t)ks * (size_t)m * (size_t)n * sizeof(float) : 0;
-}
-
-int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
-             const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n, int k,
-             void* workspace, size_t workspace_bytes, int flags, mv_stream_t stream) {
-    using namespace mv;
+static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_r,
+                      const void* ln_w, float eps, void* sum_out, int64_t ld_sum_out, int prologue,
+                      int var_from_rounded, const void* w_tiles, const void* bias,
+                      const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,
+                      int k, void* workspace, size_t workspace_bytes, int flags,
+                      mv_stream_t stream) {
     if (!x || !w_tiles || !y || m <= 0 || n <= 0 || k <= 0) return MV_ERR_INVALID_ARG;
     if (m > 64 || (n % 16) != 0 || (k % 32) != 0) return MV_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(w_tiles) || (ldx % 8) != 0 || ldx < k) return MV_ERR_INVALID_ARG;
@@ -401,6 +491,13 @@ int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
         return MV_ERR_INVALID_ARG;
     if (of32 && (!aligned16(y) || (ldy % 4) != 0)) return MV_ERR_INVALID_ARG;
     if (residual && ld_res < n) return MV_ERR_INVALID_ARG;
+    if (prologue != kProNone) {
+        if (!aligned16(ln_w)) return MV_ERR_INVALID_ARG;
+        if (prologue == kProAddNorm &&
+            (!aligned16(add_r) || !aligned16(sum_out) || (ld_add_r % 8) || (ld_sum_out % 8) ||
+             ld_add_r < k || ld_sum_out < k))
+            return MV_ERR_INVALID_ARG;
+    }
 
     GemmArgs a;
     a.x = (const uint16_t*)x;
@@ -416,6 +513,14 @@ int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
     a.k = k;
     a.nt = n / 16;
     a.kt = k / 32;
+    a.prologue = prologue;
+    a.var_from_rounded = var_from_rounded;
+    a.add_r = (const uint16_t*)add_r;
+    a.ld_add_r = ld_add_r;
+    a.ln_w = (const uint16_t*)ln_w;
+    a.eps = eps;
+    a.sum_out = (uint16_t*)sum_out;
+    a.ld_sum_out = ld_sum_out;
     a.ksplit = pick_ksplit(a.nt, a.kt);
     a.partial = nullptr;
     if (a.ksplit > 1) {
@@ -466,6 +571,53 @@ int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
         rc = check_launch();
     }
     return rc;
+}
+
+}  // namespace mv
+
+extern "C" {
+
+// Tuning hook for experiments: key 0 = workgroups per CU, key 1 = forced ksplit (0 = auto).
+int mv_wgemm_tune(int key, int value) {
+    if (key == 0 && value >= 1 && value <= 8) {
+        mv::g_tune_bpc = value;
+        return MV_OK;
+    }
+    if (key == 1 && value >= 0 && value <= mv::kMaxKsplit) {
+        mv::g_tune_ksplit = value;
+        return MV_OK;
+    }
+    return MV_ERR_INVALID_ARG;
+}
+
+size_t mv_wgemm_workspace_bytes(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
+    // slabs for the split the planner picks now; a call that later finds the
+    // workspace too small (tuning changed) runs unsplit instead of failing
+    const int ks = mv::pick_ksplit(n / 16, k / 32);
+    return ks > 1 ? (size_t)ks * (size_t)m * (size_t)n * sizeof(float) : 0;
+}
+
+int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
+             const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n, int k,
+             void* workspace, size_t workspace_bytes, int flags, mv_stream_t stream) {
+    return mv::wgemm_impl(x, ldx, nullptr, 0, nullptr, 0.f, nullptr, 0, mv::kProNone, 0, w_tiles, bias,
+                          residual, ld_res, y, ldy, m, n, k, workspace, workspace_bytes, flags,
+                          stream);
+}
+
+int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_r,
+                  const void* ln_w, float eps, void* sum_out, int64_t ld_sum_out, int norm_flags,
+                  const void* w_tiles, const void* bias, const void* residual, int64_t ld_res,
+                  void* y, int64_t ldy, int m, int n, int k, void* workspace,
+                  size_t workspace_bytes, int flags, mv_stream_t stream) {
+    if (!ln_w) return MV_ERR_INVALID_ARG;
+    if ((add_r == nullptr) != (sum_out == nullptr)) return MV_ERR_INVALID_ARG;
+    if (m > 4) return MV_ERR_UNSUPPORTED;  // the fused input transform lives in the dot form
+    return mv::wgemm_impl(x, ldx, add_r, ld_add_r, ln_w, eps, sum_out, ld_sum_out,
+                          add_r ? mv::kProAddNorm : mv::kProNorm,
+                          (norm_flags & MV_NORM_VAR_FROM_ROUNDED) ? 1 : 0, w_tiles, bias, residual,
+                          ld_res, y, ldy, m, n, k, workspace, workspace_bytes, flags, stream);
 }
 
 }  // extern "C"

@@ -113,6 +113,49 @@ def wgemm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
     return out
 
 
+def wgemm_norm(x: torch.Tensor, ln_weight: torch.Tensor, eps: float, w: StreamedWeight,
+               out: torch.Tensor, add_r: Optional[torch.Tensor] = None,
+               sum_out: Optional[torch.Tensor] = None, var_from_rounded: bool = False,
+               bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+               swiglu: bool = False, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """wgemm on rmsnorm(x [+ add_r]) * ln_weight in ONE launch (M <= 4); `sum_out` receives
+    bf16(x + add_r).  Bit-identical to rmsnorm_ / rmsnorm_residual_gemm followed by wgemm."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    m, k = x.shape
+    assert m <= 4, "fused norm prologue is built for M <= 4"
+    assert k == w.k and ln_weight.numel() == k and ln_weight.dtype == torch.bfloat16
+    assert swiglu == w.swiglu
+    ncols = w.out_features
+    assert out.shape == (m, ncols) and out.stride(1) == 1
+    flags = nv.MV_GEMM_SWIGLU if swiglu else nv.MV_GEMM_DEFAULT
+    if out.dtype == torch.float32:
+        flags |= nv.MV_GEMM_OUT_F32
+    assert (add_r is None) == (sum_out is None)
+    ld_r = ld_s = 0
+    if add_r is not None:
+        assert add_r.shape == x.shape and sum_out.shape == x.shape
+        assert add_r.dtype == torch.bfloat16 and sum_out.dtype == torch.bfloat16
+        ld_r = add_r.stride(0) if m > 1 else k
+        ld_s = sum_out.stride(0) if m > 1 else k
+    ld_res = 0
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape == (m, w.n)
+        ld_res = residual.stride(0) if m > 1 else w.n
+    L = nv.lib()
+    if workspace is None:
+        workspace = gemm_workspace(x.device, L.mv_wgemm_workspace_bytes(m, w.n, k))
+    ws_ptr = workspace.data_ptr() if workspace is not None else None
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    ldx = x.stride(0) if m > 1 else max(k, x.stride(0))
+    ldy = out.stride(0) if m > 1 else max(ncols, out.stride(0))
+    nv.check("mv_wgemm_norm", L.mv_wgemm_norm(
+        x.data_ptr(), ldx, nv.ptr(add_r), ld_r, ln_weight.data_ptr(), float(eps), nv.ptr(sum_out),
+        ld_s, nv.MV_NORM_VAR_FROM_ROUNDED if var_from_rounded else 0, w.tiles.data_ptr(),
+        nv.ptr(bias), nv.ptr(residual), ld_res, out.data_ptr(), ldy, m, w.n, k, ws_ptr, ws_bytes,
+        flags, nv.stream_ptr()))
+    return out
+
+
 def embedding(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """out[r] = table[ids[r]] (model.transformer.wte(input_ids), model_graph.py:196)."""
     assert table.is_cuda and ids.is_cuda and out.is_cuda

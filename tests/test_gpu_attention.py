@@ -178,3 +178,23 @@ def test_softmax_spike_forces_rescale(mv):
     check_output(got, case, what="spike, 1 split")
     got, want, _, _ = run_both(case, 5)
     check_output(got, case, what="spike, 5 splits")
+
+
+def test_in_kernel_merge_equals_second_kernel_merge(mv):
+    """Split merge by the last-arriving workgroup vs the separate merge kernel: same bits, and the
+    arrival counters return to zero (the second call would otherwise never merge)."""
+    from micro_vllm_amd import _native as nv
+
+    case = make_case(6, 8, 2, 128, 256, [0, 63, 64, 1000, 2049, 4096], seed=55)
+    outs = {}
+    try:
+        for mode in (1, 0, 1):
+            assert nv.lib().mv_paged_attn_tune(0, mode) == 0
+            for splits in (2, 7, 64):
+                got, _, _, _ = run_both(case, splits)
+                outs.setdefault(splits, []).append(got.clone())
+    finally:
+        nv.lib().mv_paged_attn_tune(0, 1)
+    for splits, lst in outs.items():
+        assert torch.equal(lst[0], lst[1]) and torch.equal(lst[0], lst[2]), splits
+        check_output(lst[0], case, what=f"merge splits={splits}")

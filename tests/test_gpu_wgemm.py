@@ -143,3 +143,50 @@ def test_wgemm_rejects_bad_shapes(mv):
     big = torch.zeros(65, 128, dtype=torch.bfloat16, device=DEV)
     with pytest.raises(AssertionError):
         wgemm(big, sw, torch.empty(65, 64, dtype=torch.bfloat16, device=DEV))
+
+
+@pytest.mark.parametrize("m", [1, 2, 3, 4])
+@pytest.mark.parametrize("n,k,swiglu", [(512, 1024, False), (6144, 4096, False), (1408, 512, True),
+                                        (256, 14336, False)])
+def test_wgemm_norm_prologue_is_bit_identical_to_two_kernels(mv, m, n, k, swiglu):
+    """rmsnorm_ -> wgemm and rmsnorm_residual_gemm -> wgemm against their one-launch forms."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm, wgemm_norm
+    from micro_vllm_amd.kernel.rmsnorm_add import rmsnorm_
+    from micro_vllm_amd.kernel.rmsnorm_residual import rmsnorm_residual_gemm
+
+    g = torch.Generator().manual_seed(m * 31 + n + k)
+    x = (torch.randn(m, k, generator=g) * 2).to(torch.bfloat16).to(DEV)
+    r = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    lw = (1 + 0.2 * torch.randn(k, generator=g)).to(torch.bfloat16).to(DEV)
+    w = (torch.randn(n, k, generator=g) * 0.03).to(torch.bfloat16)
+    if swiglu:
+        sw = StreamedWeight.from_up_gate(w[:n // 2].to(DEV), w[n // 2:].to(DEV))
+    else:
+        sw = StreamedWeight.from_linear(w.to(DEV))
+    ncols = sw.out_features
+    bias = None if swiglu else torch.randn(n, generator=g).to(torch.bfloat16).to(DEV)
+    eps = 1e-5
+
+    def out():
+        return torch.empty(m, ncols, dtype=torch.bfloat16, device=DEV)
+
+    # plain norm
+    normed = rmsnorm_(x, lw, torch.empty_like(x), eps)
+    two = wgemm(normed, sw, out(), bias=bias, swiglu=swiglu)
+    one = wgemm_norm(x, lw, eps, sw, out(), bias=bias, swiglu=swiglu)
+    assert torch.equal(one, two)
+    # add + norm (variance from the un-rounded sum) with the sum written out
+    n2, s2 = torch.empty_like(x), torch.empty_like(x)
+    rmsnorm_residual_gemm(x, r, lw, n2, s2, eps)
+    two = wgemm(n2, sw, out(), bias=bias, swiglu=swiglu)
+    s1 = torch.empty_like(x)
+    one = wgemm_norm(x, lw, eps, sw, out(), add_r=r, sum_out=s1, bias=bias, swiglu=swiglu)
+    assert torch.equal(s1, s2) and torch.equal(one, two)
+    # add (rounded) then norm of the rounded sum: h = a.add_(r); rmsnorm_(h)
+    from micro_vllm_amd.kernel.linear import add_
+    h = add_(x.clone(), r)
+    two = wgemm(rmsnorm_(h, lw, torch.empty_like(x), eps), sw, out(), bias=bias, swiglu=swiglu)
+    s3 = torch.empty_like(x)
+    one = wgemm_norm(x, lw, eps, sw, out(), add_r=r, sum_out=s3, var_from_rounded=True, bias=bias,
+                     swiglu=swiglu)
+    assert torch.equal(s3, h) and torch.equal(one, two)
