@@ -349,42 +349,65 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
         for (int sp = 0; sp < ns; ++sp) w[sp] *= inv;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < G * D; o += kAT) {
-        const int g = o / D, d = o - g * D;
-        const int hq = kvh * G + g;
-        const unsigned int* src =
-            reinterpret_cast<const unsigned int*>(a.part_o + (((int64_t)b * a.hq + hq) * ns) * D + d);
+    // One (head, 4 consecutive d) item per thread group; the group's PARTS threads take
+    // interleaved splits with 16-byte sc1 loads, all issued before the first use, so the
+    // merge costs about one memory round trip.  Partial sums meet in LDS in a fixed order.
+    constexpr int ITEMS = G * D / 4;
+    constexpr int PARTS = kAT / ITEMS >= 1 ? kAT / ITEMS : 1;
+    constexpr int kMU = 16;  // loads in flight per thread
+    float* psum = lds + G * 128;  // [PARTS][ITEMS][4], past the weights (nsplit <= 128)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.part_o + ((int64_t)b * a.hq + kvh * G) * ns * D, 0, G * ns * D * 4, 0x00020000);
+    for (int it = threadIdx.x; it < ITEMS * PARTS; it += kAT) {
+        const int item = it % ITEMS, part = it / ITEMS;
+        const int g = item / (D / 4), d4 = (item - g * (D / 4)) * 4;
         const float* w = wts + g * ns;
-        float acc_o = 0.f;
-        int sp = 0;
-        for (; sp + 8 <= ns; sp += 8) {
-            float v[8];
+        f32x4_t acc_o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int s0 = part; s0 < ns; s0 += PARTS * kMU) {
+            u32x4_t v[kMU];
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                v[j] = __uint_as_float(__hip_atomic_load(const_cast<unsigned int*>(src + (int64_t)(sp + j) * D),
-                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            for (int j = 0; j < kMU; ++j) {
+                const int sp = min(s0 + j * PARTS, ns - 1);
+                v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((g * ns + sp) * D + d4) * 4, 0, 16 /*sc1*/);
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc_o = __builtin_fmaf(w[sp + j], v[j], acc_o);
+            for (int j = 0; j < kMU; ++j) {
+                const int sp = s0 + j * PARTS;
+                const float wj = sp < ns ? w[sp] : 0.f;
+                acc_o[0] = __builtin_fmaf(wj, __uint_as_float(v[j].x), acc_o[0]);
+                acc_o[1] = __builtin_fmaf(wj, __uint_as_float(v[j].y), acc_o[1]);
+                acc_o[2] = __builtin_fmaf(wj, __uint_as_float(v[j].z), acc_o[2]);
+                acc_o[3] = __builtin_fmaf(wj, __uint_as_float(v[j].w), acc_o[3]);
+            }
         }
-        for (; sp < ns; ++sp)
-            acc_o = __builtin_fmaf(
-                w[sp],
-                __uint_as_float(__hip_atomic_load(const_cast<unsigned int*>(src + (int64_t)sp * D),
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)),
-                acc_o);
-        a.out[((int64_t)b * a.hq + hq) * D + d] = (uint16_t)f32_to_bf16_bits(acc_o);
+        *reinterpret_cast<f32x4_t*>(psum + (part * ITEMS + item) * 4) = acc_o;
+    }
+    __syncthreads();
+    for (int item = threadIdx.x; item < ITEMS; item += kAT) {
+        const int g = item / (D / 4), d4 = (item - g * (D / 4)) * 4;
+        f32x4_t t = *reinterpret_cast<const f32x4_t*>(psum + item * 4);
+#pragma unroll
+        for (int p = 1; p < PARTS; ++p) t += *reinterpret_cast<const f32x4_t*>(psum + (p * ITEMS + item) * 4);
+        uint2 o2;
+        o2.x = pack_bf16x2(t[0], t[1]);
+        o2.y = pack_bf16x2(t[2], t[3]);
+        *reinterpret_cast<uint2*>(a.out + ((int64_t)b * a.hq + kvh * G + g) * D + d4) = o2;
     }
     if (threadIdx.x == 0)  // leave the counter at zero for the next launch
         __hip_atomic_store(a.arrive + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// out[b,h,:] = sum_s w_s o_s / sum_s w_s,  w_s = 2^(lse_s - max lse)
-template <int D>
+// Second-launch form of the split merge (used when the arrival counters are unavailable or
+// switched off).  Same arithmetic and summation order as the in-kernel merge: PARTS interleaved
+// partial sums per output, added in order.
+template <int D, int G>
 __global__ __launch_bounds__(D) void paged_attn_combine_kernel(const float* __restrict__ part_lse,
                                                                const float* __restrict__ part_o,
                                                                uint16_t* __restrict__ out,
                                                                int nsplit) {
-    const int64_t bh = blockIdx.x;
+    constexpr int ITEMS = G * D / 4;
+    constexpr int PARTS = kAT / ITEMS >= 1 ? kAT / ITEMS : 1;
+    const int64_t bh = blockIdx.x;  // (b, query head)
     const int d = threadIdx.x;
     const float* lse = part_lse + bh * nsplit;
     float mx = kNegBig;
@@ -392,10 +415,14 @@ __global__ __launch_bounds__(D) void paged_attn_combine_kernel(const float* __re
     float wsum = 0.f;
     for (int s = 0; s < nsplit; ++s) wsum += __builtin_amdgcn_exp2f(lse[s] - mx);
     const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
-    float o = 0.f;  // same arithmetic and order as the in-kernel merge: results are identical
-    for (int s = 0; s < nsplit; ++s)
-        o = __builtin_fmaf(__builtin_amdgcn_exp2f(lse[s] - mx) * inv, part_o[(bh * nsplit + s) * D + d], o);
-    out[bh * D + d] = (uint16_t)f32_to_bf16_bits(o);
+    float total = 0.f;
+    for (int p = 0; p < PARTS; ++p) {
+        float o = 0.f;
+        for (int s = p; s < nsplit; s += PARTS)
+            o = __builtin_fmaf(__builtin_amdgcn_exp2f(lse[s] - mx) * inv, part_o[(bh * nsplit + s) * D + d], o);
+        total = p == 0 ? o : total + o;
+    }
+    out[bh * D + d] = (uint16_t)f32_to_bf16_bits(total);
 }
 
 // Arrival counters of the in-kernel split merge.  Zero at load time and returned to zero by the
@@ -434,7 +461,7 @@ static int launch_decode(const AttnArgs& a, hipStream_t s) {
                        lds, s, a);
     int rc = check_launch();
     if (rc != MV_OK || a.nsplit == 1 || a.arrive != nullptr) return rc;
-    hipLaunchKernelGGL((paged_attn_combine_kernel<D>), dim3(a.bs * a.hq), dim3(D), 0, s,
+    hipLaunchKernelGGL((paged_attn_combine_kernel<D, G>), dim3(a.bs * a.hq), dim3(D), 0, s,
                        a.part_lse, a.part_o, a.out, a.nsplit);
     return check_launch();
 }
@@ -546,7 +573,8 @@ int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, c
         a.part_o = (float*)((char*)workspace + align_up(rows * sizeof(float), 256));
     }
     a.arrive = nullptr;
-    if (num_splits > 1 && g_tune_inkernel_merge && bs * hkv <= kMaxArrive) a.arrive = arrive_counters();
+    if (num_splits > 1 && num_splits <= 128 && g_tune_inkernel_merge && bs * hkv <= kMaxArrive)
+        a.arrive = arrive_counters();
     const int g = hq / hkv;
     hipStream_t s = (hipStream_t)stream;
     return d == 128 ? dispatch_g<128>(a, g, s) : dispatch_g<64>(a, g, s);

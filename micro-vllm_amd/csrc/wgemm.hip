@@ -30,7 +30,7 @@ constexpr int kGT = kGW * kWave;     // 512 threads
 constexpr int kU = 8;                // tiles per wave per pipeline stage
 constexpr int kMaxKsplit = 8;
 
-static int g_tune_bpc = 2;      // workgroups per CU the grid is sized for
+static int g_tune_bpc = 1;      // workgroups per CU the grid is sized for
 static int g_tune_ksplit = 0;   // 0 = heuristic
 
 enum { kProNone = 0, kProNorm = 1, kProAddNorm = 2 };
@@ -432,19 +432,17 @@ static int pick_ksplit(int nt, int kt) {
         while (ks > 1 && (kt % ks) != 0) --ks;
         return ks;
     }
+    // Measured on MI355X (tools/bench_wgemm.py, M=1): whole strips beat every k-split for all
+    // four decode projections (QKV 11.8 vs 14.8 us, O 8.0 vs 11.4, gate/up 38.8 vs 48.5, down
+    // 20.8 vs 23.7): the second launch that adds the slabs costs more than the imbalance of
+    // 1.5 strips per CU.  Splitting only pays when there are far fewer strips than CUs.
     const int cus = num_cus();
     int best = 1;
-    long best_cost = -1;
-    for (int ks = 1; ks <= kMaxKsplit; ks *= 2) {
+    for (int ks = 2; ks <= kMaxKsplit; ks *= 2) {
         if (kt % ks) break;
-        const int ktps = kt / ks;
-        if (ks > 1 && ktps < 2 * kGW) break;
-        const long rounds = ((long)nt * ks + cus - 1) / cus;
-        const long cost = rounds * ktps + (ks > 1 ? 40 : 0);
-        if (best_cost < 0 || cost < best_cost) {
-            best_cost = cost;
-            best = ks;
-        }
+        if (kt / ks < 4 * kGW) break;          // keep >= 4 tiles per wave
+        if ((long)nt * best * 2 > cus) break;  // already at least half the CUs busy
+        best = ks;
     }
     return best;
 }

@@ -111,7 +111,7 @@ def test_wgemm_ksplit_variants_agree_and_are_deterministic(mv):
             assert_close_bf16(y, want, atol=1e-3, rtol=2 ** -7)
     finally:
         nv.lib().mv_wgemm_tune(1, 0)
-        nv.lib().mv_wgemm_tune(0, 2)
+        nv.lib().mv_wgemm_tune(0, 1)
 
 
 def test_wgemm_strided_rows_and_big_k(mv):
