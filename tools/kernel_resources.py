@@ -18,7 +18,7 @@ def main():
     cur = None
     rows = {}
     for line in out.splitlines():
-        m = re.search(r"remark: +(Function Name|[A-Za-z ]+): +(.+?) \[-Rpass", line)
+        m = re.search(r"remark: +([^:]+): +(.+?) \[-Rpass", line)
         if not m:
             if "error" in line:
                 print(line)
