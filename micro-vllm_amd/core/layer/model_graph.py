@@ -30,6 +30,36 @@ from ...kernel.swiglu import swiglu_gemm
 logger = logging.getLogger(__name__)
 
 
+def shard_block_weights(block, num_heads_total, kv_heads_total, head_size, rank, world):
+    """One rank's slice of a transformer block, exactly as the reference cuts it
+    (core/layer/model_graph.py:95-116): column-parallel QKV and gate/up = rows of the [out,in]
+    weights (q, k and v each chunked separately), row-parallel O and down = their columns; the
+    QKV bias is sliced like the QKV rows and nothing is added on the row-parallel side.
+    Returns [out,in] tensors (views where possible); no device work, usable on CPU."""
+    q_dim, kv_dim = num_heads_total * head_size, kv_heads_total * head_size
+
+    def rows(w):
+        return w.chunk(world, dim=0)[rank]
+
+    def cols(w):
+        return w.chunk(world, dim=1)[rank]
+
+    w_q, w_k, w_v = block.attn.c_attn.weight.split([q_dim, kv_dim, kv_dim], dim=0)
+    out = {
+        "qkv": torch.cat([rows(w_q), rows(w_k), rows(w_v)], dim=0),
+        "qkv_b": None,
+        "o": cols(block.attn.c_proj.weight),
+        "up": rows(block.mlp.w1.weight),
+        "gate": rows(block.mlp.w2.weight),
+        "d": cols(block.mlp.c_proj.weight),
+    }
+    b = block.attn.c_attn.bias
+    if b is not None:
+        b_q, b_k, b_v = b.split([q_dim, kv_dim, kv_dim], dim=0)
+        out["qkv_b"] = torch.cat([rows(b_q), rows(b_k), rows(b_v)], dim=0)
+    return out
+
+
 class HipGraph:
     """An instantiated hipGraph (mv_graph_* of the C ABI)."""
 
@@ -89,33 +119,18 @@ class ModelGraphRunner:
         cfg = self.model.config
         g_heads = cfg.num_attention_heads
         g_kv = getattr(cfg, "num_key_value_heads", g_heads)
-        q_dim, kv_dim = g_heads * self.head_size, g_kv * self.head_size
-        ws, rk = self.world_size, self.rank
         dev = self.device
-
-        def shard0(w):
-            return w.chunk(ws, dim=0)[rk]
-
-        def shard1(w):
-            return w.chunk(ws, dim=1)[rk]
-
         for block in self.model.transformer.h:
-            w1, w2 = block.mlp.w1.weight.to(dev), block.mlp.w2.weight.to(dev)
+            sh = shard_block_weights(block, g_heads, g_kv, self.head_size, self.rank, self.world_size)
+            up, gate = sh["up"].to(dev), sh["gate"].to(dev)
             if self.fused:
-                block.mlp._gu = StreamedWeight.from_up_gate(shard0(w1), shard0(w2))
+                block.mlp._gu = StreamedWeight.from_up_gate(up, gate)
             else:
-                block.mlp._gu = StreamedWeight.from_linear(torch.cat([shard0(w1), shard0(w2)], dim=0))
-            block.mlp._d = StreamedWeight.from_linear(shard1(block.mlp.c_proj.weight.to(dev)).contiguous())
-            block.attn._o = StreamedWeight.from_linear(shard1(block.attn.c_proj.weight.to(dev)).contiguous())
-
-            w_qkv, b_qkv = block.attn.c_attn.weight.to(dev), block.attn.c_attn.bias
-            w_q, w_k, w_v = w_qkv.split([q_dim, kv_dim, kv_dim], dim=0)
-            block.attn._qkv_w = StreamedWeight.from_linear(
-                torch.cat([shard0(w_q), shard0(w_k), shard0(w_v)], dim=0))
-            block.attn._qkv_b = None
-            if b_qkv is not None:
-                b_q, b_k, b_v = b_qkv.to(dev).split([q_dim, kv_dim, kv_dim], dim=0)
-                block.attn._qkv_b = torch.cat([shard0(b_q), shard0(b_k), shard0(b_v)], dim=0).contiguous()
+                block.mlp._gu = StreamedWeight.from_linear(torch.cat([up, gate], dim=0))
+            block.mlp._d = StreamedWeight.from_linear(sh["d"].to(dev).contiguous())
+            block.attn._o = StreamedWeight.from_linear(sh["o"].to(dev).contiguous())
+            block.attn._qkv_w = StreamedWeight.from_linear(sh["qkv"].to(dev))
+            block.attn._qkv_b = None if sh["qkv_b"] is None else sh["qkv_b"].to(dev).contiguous()
             block.ln_1.weight = block.ln_1.weight.to(dev)
             block.ln_2.weight = block.ln_2.weight.to(dev)
             if self.release_source_weights:
@@ -300,10 +315,15 @@ class ModelGraphRunner:
                     self.decode(self._input_ids[:bs], bs, cache_manager)
                 side.synchronize()
                 if use_torch_graph:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=side):
-                        self.decode(self._input_ids[:bs], bs, cache_manager)
-                    self._graphs[bs] = g
+                    try:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=side):
+                            self.decode(self._input_ids[:bs], bs, cache_manager)
+                        self._graphs[bs] = g
+                    except Exception as e:  # collective not capturable here: run this bs eagerly
+                        logger.warning("graph capture with collectives failed for bs=%d (%r); "
+                                       "decode will launch eagerly", bs, e)
+                        torch.cuda.synchronize()
                 else:
                     import ctypes
                     nv.check("mv_graph_begin_capture", nv.lib().mv_graph_begin_capture(side.cuda_stream))

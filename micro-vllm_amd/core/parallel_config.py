@@ -20,7 +20,7 @@ def setup():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world > 1 and not dist.is_initialized():
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and os.environ.get("MVLLM_DIST_BACKEND", "nccl") != "gloo":
             local = int(os.environ.get("LOCAL_RANK", rank))
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
@@ -54,7 +54,15 @@ def all_reduce(input_):
     """In-place SUM over the tensor-parallel ranks on the current stream; returns its argument."""
     if get_world_size() == 1:
         return input_
-    dist.all_reduce(input_, group=get_group() or dist.group.WORLD)
+    group = get_group() or dist.group.WORLD
+    if dist.get_backend(group) == "gloo":
+        # gloo is the rehearsal backend (CPU ranks, or several ranks sharing one GPU in tests):
+        # reduce on the host in fp32 and round once
+        tmp = input_.detach().float().cpu()
+        dist.all_reduce(tmp, group=group)
+        input_.copy_(tmp)
+        return input_
+    dist.all_reduce(input_, group=group)
     return input_
 
 

@@ -1,0 +1,109 @@
+"""The decode runner's tensor-parallel wiring with two ranks sharing the one GPU of the test box:
+HIP kernels compute each rank's shard, gloo carries the two all-reduces per layer (RCCL needs one
+GPU per rank).  Checks slicing, the deferred residual add in the next QKV prologue, and that both
+ranks end with the oracle's logits."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, fused, bs, out_q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVLLM_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import micro_vllm_amd  # noqa: F401
+    from micro_vllm_amd.core import parallel_config as pc
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+    from micro_vllm_amd.core.layer.model_graph import ModelGraphRunner
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    torch.cuda.set_device(0)
+    pc.setup()
+    dev = "cuda"
+    cfg = SHAPES["tiny-gqa"]
+    model = build_synthetic_model(cfg, "cpu", seed=1234, qkv_bias=True).to(dev)
+    hkv = cfg.num_key_value_heads // world
+    runner = ModelGraphRunner(model, cfg.num_hidden_layers, cfg.num_attention_heads // world,
+                              cfg.head_dim, hkv, cfg.hidden_size, cfg.intermediate_size // world, dev,
+                              max_batch_size=8, fused=fused)
+    assert runner.world_size == world and runner.rank == rank
+    mgr = KVCacheManager(8, 256, cfg.num_hidden_layers, hkv, cfg.head_dim, dtype=torch.bfloat16,
+                         device=dev, max_tokens=1024, max_batch_size=8)
+    g = torch.Generator().manual_seed(5)
+    lens = [3, 300, 40, 255, 17, 64][:bs]
+    for li in range(cfg.num_hidden_layers):
+        fk = torch.randn(8, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
+        fv = torch.randn(8, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
+        mgr.k_caches[li].copy_(fk[:, :, rank * hkv:(rank + 1) * hkv])
+        mgr.v_caches[li].copy_(fv[:, :, rank * hkv:(rank + 1) * hkv])
+    for sid, L in enumerate(lens):
+        mgr.alloc(sid, L)
+        mgr.append(sid)
+    mgr.cache_batch_data(list(range(bs)), [L + 1 for L in lens])
+    ids = torch.arange(bs, dtype=torch.long) * 13 + 5
+    runner._input_ids[:bs] = ids.to(dev)
+    logits = runner.decode(runner._input_ids[:bs], bs, mgr).float().cpu()
+    bt = mgr._block_table_buffer[:bs].cpu()
+    pc.barrier()
+    out_q.put((rank, logits.numpy(), bt.numpy()))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fused,bs", [(True, 2), (False, 2), (True, 6)])
+def test_two_ranks_on_one_gpu_match_the_oracle(fused, bs):
+    sys.path.insert(0, ROOT)
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+    from oracle.ref_model import RefRunner
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, fused, bs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, lg, bt = q.get(timeout=300)
+        got[r] = (torch.from_numpy(lg), torch.from_numpy(bt))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(got[0][0], got[1][0]), "ranks disagree"
+    assert torch.equal(got[0][1], got[1][1])
+
+    cfg = SHAPES["tiny-gqa"]
+    model = build_synthetic_model(cfg, "cpu", seed=1234, qkv_bias=True)
+    g = torch.Generator().manual_seed(5)
+    fks, fvs = [], []
+    for li in range(cfg.num_hidden_layers):
+        fks.append(torch.randn(8, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16))
+        fvs.append(torch.randn(8, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16))
+    hkv = cfg.num_key_value_heads // 2
+    caches = [([t[:, :, r * hkv:(r + 1) * hkv].contiguous() for t in fks],
+               [t[:, :, r * hkv:(r + 1) * hkv].contiguous() for t in fvs]) for r in range(2)]
+    lens = [3, 300, 40, 255, 17, 64][:bs]
+    sl = torch.tensor([L + 1 for L in lens], dtype=torch.int32)
+    ids = torch.arange(bs, dtype=torch.long) * 13 + 5
+    want = RefRunner(model, cfg.head_dim, world=2).decode(ids, caches, sl, got[0][1]).float()
+    err = (got[0][0] - want).abs()
+    tol = 2.0 ** -7 * float(want.abs().max()) + 2 ** -7 * want.abs()
+    assert bool((err <= tol).all()), f"max err {err.max().item()}"
+    assert err.mean().item() <= 2e-3
+    assert bool((got[0][0].argmax(-1) == want.argmax(-1)).all())

@@ -1,0 +1,125 @@
+"""Tensor-parallel host logic with world_size 2 over gloo on CPU: process-group set-up, the
+reference's weight slicing, and all_reduce placement, checked against the single-rank oracle."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVLLM_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(2)
+    import micro_vllm_amd  # noqa: F401
+    from micro_vllm_amd.core import parallel_config as pc
+    from micro_vllm_amd.core.layer.model_graph import shard_block_weights
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+    from oracle.ref_attention import flash_attn_with_kvcache_ref
+    from oracle.ref_ops import (BF16, linear_ref, rmsnorm_ref, rmsnorm_residual_ref,
+                                rotary_tables_ref, swiglu_ref)
+
+    pc.setup()
+    assert pc.get_world_size() == world and pc.get_rank() == rank and pc.rank0() == (rank == 0)
+    cfg = SHAPES["tiny-gqa"]
+    model = build_synthetic_model(cfg, "cpu", seed=1234, qkv_bias=True)
+    D, hq, hkv = cfg.head_dim, cfg.num_attention_heads // world, cfg.num_key_value_heads // world
+    cos, sin = rotary_tables_ref(D, 8192)
+    g = torch.Generator().manual_seed(5)
+    # identical full caches on every rank; each rank keeps its own kv heads
+    n_pages, ctx = 4, [3, 300]
+    full_k = [torch.randn(n_pages, 256, cfg.num_key_value_heads, D, generator=g).to(BF16) for _ in range(2)]
+    full_v = [torch.randn(n_pages, 256, cfg.num_key_value_heads, D, generator=g).to(BF16) for _ in range(2)]
+    kc = [t[:, :, rank * hkv:(rank + 1) * hkv].contiguous() for t in full_k]
+    vc = [t[:, :, rank * hkv:(rank + 1) * hkv].contiguous() for t in full_v]
+    bt = torch.tensor([[2, -1], [0, 3]], dtype=torch.int32)
+    sl = torch.tensor(ctx, dtype=torch.int32)
+    ids = torch.tensor([7, 99])
+    h = model.transformer.wte.weight[ids]
+    for li, block in enumerate(model.transformer.h):
+        sh = shard_block_weights(block, cfg.num_attention_heads, cfg.num_key_value_heads, D, rank, world)
+        normed = rmsnorm_ref(h, block.ln_1.weight, block.ln_1.eps)
+        qkv = linear_ref(normed, sh["qkv"], sh["qkv_b"])
+        q = qkv[:, :hq * D].reshape(2, hq, D)
+        k = qkv[:, hq * D:(hq + hkv) * D].reshape(2, hkv, D)
+        v = qkv[:, (hq + hkv) * D:].reshape(2, hkv, D)
+        attn = flash_attn_with_kvcache_ref(q.unsqueeze(1), kc[li], vc[li], k.unsqueeze(1), v.unsqueeze(1),
+                                           cos, sin, sl, bt, p_bf16=False).squeeze(1)
+        attn_out = pc.all_reduce(linear_ref(attn.reshape(2, -1), sh["o"]))
+        normed, residual = rmsnorm_residual_ref(attn_out, h, block.ln_2.weight, block.ln_2.eps)
+        gu = linear_ref(normed, torch.cat([sh["up"], sh["gate"]], 0))
+        mlp = pc.all_reduce(linear_ref(swiglu_ref(gu), sh["d"]))
+        h = (mlp.float() + residual.float()).to(BF16)
+    pc.barrier()
+    out_q.put((rank, h.float().numpy()))   # by value: the process exits right after
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_the_oracle():
+    sys.path.insert(0, ROOT)
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+    from oracle.ref_model import RefRunner
+    from oracle.ref_ops import BF16
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    outs = {r: torch.from_numpy(a) for r, a in (q.get(timeout=240) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(outs[0], outs[1]), "ranks disagree after the all-reduces"
+
+    cfg = SHAPES["tiny-gqa"]
+    model = build_synthetic_model(cfg, "cpu", seed=1234, qkv_bias=True)
+    g = torch.Generator().manual_seed(5)
+    D = cfg.head_dim
+    full_k = [torch.randn(4, 256, cfg.num_key_value_heads, D, generator=g).to(BF16) for _ in range(2)]
+    full_v = [torch.randn(4, 256, cfg.num_key_value_heads, D, generator=g).to(BF16) for _ in range(2)]
+    bt = torch.tensor([[2, -1], [0, 3]], dtype=torch.int32)
+    sl = torch.tensor([3, 300], dtype=torch.int32)
+    ids = torch.tensor([7, 99])
+    for world in (1, 2):
+        ref = RefRunner(model, D, world=world)
+        hkv = cfg.num_key_value_heads // world
+        caches = [([t[:, :, r * hkv:(r + 1) * hkv].contiguous() for t in full_k],
+                   [t[:, :, r * hkv:(r + 1) * hkv].contiguous() for t in full_v]) for r in range(world)]
+        trace = []
+        ref.decode(ids, caches, sl, bt, trace=trace)
+        want = trace[-1].float()
+        err = (outs[0] - want).abs()
+        if world == 2:   # same arithmetic, same reduction: identical
+            assert torch.equal(outs[0], want)
+        else:            # sharded sums round differently: bf16 resolution of the hidden state
+            assert bool((err <= 2.0 ** -7 * float(want.abs().max()) + 2 ** -7 * want.abs()).all()), err.max()
+
+
+def test_single_process_is_a_no_op():
+    sys.path.insert(0, ROOT)
+    import micro_vllm_amd  # noqa: F401
+    from micro_vllm_amd.core import parallel_config as pc
+
+    for k in ("RANK", "WORLD_SIZE"):
+        os.environ.pop(k, None)
+    pc.setup()
+    assert pc.get_world_size() == 1 and pc.get_rank() == 0 and pc.rank0()
+    t = torch.ones(3)
+    assert pc.all_reduce(t) is t
+    pc.barrier()
