@@ -121,8 +121,9 @@ int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_
                   size_t workspace_bytes, int flags, mv_stream_t stream);
 
 /* Launch-shape knobs for experiments (no counterpart in the reference):
- * key 0 = workgroups per CU the grid is sized for (1..8, default 1);
- * key 1 = forced number of k-slices per strip (0 = pick automatically). */
+ * key 0 = workgroups per CU the grid is sized for (1..8; 0 = planner, the default);
+ * key 1 = forced number of k-slices per strip (0 = pick automatically);
+ * key 2 = waves per workgroup of the M <= 4 kernel (8 or 16; 0 = planner). */
 int mv_wgemm_tune(int key, int value);
 
 /* ---------------------------------------------------- paged attention */

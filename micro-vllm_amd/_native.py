@@ -8,7 +8,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmvllm.so")
+# MVLLM_LIB selects another build of the same ABI (kernel-parameter experiments)
+LIB_PATH = os.environ.get("MVLLM_LIB") or os.path.join(_HERE, "lib", "libmvllm.so")
 
 MV_OK = 0
 MV_ERR_INVALID_ARG = -1

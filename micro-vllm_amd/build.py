@@ -53,6 +53,32 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def build_variant(name, defines, only=("wgemm.hip",), verbose=False):
+    """A second library `lib/libmvllm_<name>.so` with extra -D flags for the listed sources (the
+    rest are reused from the main build); select it at run time with MVLLM_LIB=<path>."""
+    build(verbose=verbose)
+    hipcc = _hipcc()
+    objs = []
+    for s in SOURCES:
+        src = os.path.join(CSRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
+        if s in only:
+            obj = os.path.join(OBJDIR, s.replace(".hip", f".{name}.o"))
+            cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", src, "-o", obj]
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(r.stdout)
+        objs.append(obj)
+    out = os.path.join(LIBDIR, f"libmvllm_{name}.so")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(r.stdout)
+    return out
+
+
 def build(force=False, verbose=True, jobs=None):
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)

@@ -25,12 +25,12 @@
 
 namespace mv {
 
-constexpr int kGW = 8;               // waves per workgroup
-constexpr int kGT = kGW * kWave;     // 512 threads
-constexpr int kU = 8;                // tiles per wave per pipeline stage
+constexpr int kGW = 8;           // waves per workgroup, MFMA form
+constexpr int kGT = kGW * kWave;
 constexpr int kMaxKsplit = 8;
 
-static int g_tune_bpc = 1;      // workgroups per CU the grid is sized for
+static int g_tune_bpc = 0;      // workgroups per CU the grid is sized for (0 = planner)
+static int g_tune_waves = 0;    // waves per workgroup of the dot form: 8 or 16 (0 = planner)
 static int g_tune_ksplit = 0;   // 0 = heuristic
 
 enum { kProNone = 0, kProNorm = 1, kProAddNorm = 2 };
@@ -83,10 +83,12 @@ struct UnitCtx {
     const uint4* wbase;
 };
 
-template <int M>
-__global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
+// GW waves per workgroup, each keeping two stages of U weight tiles in flight.
+template <int M, int GW, int U>
+__global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
+    constexpr int GT = GW * kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // layout: x rows [M][K] bf16 | 16 zero bytes | red [kGW][M][16] fp32
+    // layout: x rows [M][K] bf16 | 16 zero bytes | red [GW][M][16] fp32
     uint16_t* xs = reinterpret_cast<uint16_t*>(smem);
     const int zero_off = M * a.k * 2;
     float* red = reinterpret_cast<float*>(smem + zero_off + 16);
@@ -101,25 +103,25 @@ __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
         c.ks = u - c.nt * a.ksplit;
         c.kt0 = c.ks * a.ktps;
         const int kt1 = min(a.kt, c.kt0 + a.ktps);
-        c.ntile = (kt1 - c.kt0 - wid + kGW - 1) / kGW;  // tiles of this wave (may be <= 0)
-        c.nchunk = (c.ntile + kU - 1) / kU;
+        c.ntile = (kt1 - c.kt0 - wid + GW - 1) / GW;  // tiles of this wave (may be <= 0)
+        c.nchunk = (c.ntile + U - 1) / U;
         c.last = max(c.ntile - 1, 0);
         c.wbase = a.w + ((int64_t)c.nt * a.kt + c.kt0 + wid) * 64 + lane;
         return c;
     };
-    auto load = [&](uint4(&buf)[kU], const UnitCtx& c, int chunk) {
+    auto load = [&](uint4(&buf)[U], const UnitCtx& c, int chunk) {
 #pragma unroll
-        for (int i = 0; i < kU; ++i) {
-            const int t = min(chunk * kU + i, c.last);  // clamp: always a valid address
-            buf[i] = ld16_nt(c.wbase + (int64_t)t * (kGW * 64));
+        for (int i = 0; i < U; ++i) {
+            const int t = min(chunk * U + i, c.last);  // clamp: always a valid address
+            buf[i] = ld16_nt(c.wbase + (int64_t)t * (GW * 64));
         }
     };
-    auto compute = [&](const uint4(&buf)[kU], const UnitCtx& c, int chunk, float(&acc)[M]) {
+    auto compute = [&](const uint4(&buf)[U], const UnitCtx& c, int chunk, float(&acc)[M]) {
 #pragma unroll
-        for (int i = 0; i < kU; ++i) {
-            const int t = chunk * kU + i;
+        for (int i = 0; i < U; ++i) {
+            const int t = chunk * U + i;
             // byte offset of this lane's 8 x values; out-of-range tiles read zeros
-            const int xoff = (t < c.ntile) ? ((c.kt0 + wid + t * kGW) * 32 + q * 8) * 2 : -1;
+            const int xoff = (t < c.ntile) ? ((c.kt0 + wid + t * GW) * 32 + q * 8) * 2 : -1;
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const int off = (xoff < 0) ? zero_off : m * a.k * 2 + xoff;
@@ -136,13 +138,13 @@ __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
     // touching x, so their HBM latency overlaps the input transform below.
     int u = blockIdx.x;
     UnitCtx cur = setup(u);
-    uint4 bufA[kU], bufB[kU];
+    uint4 bufA[U], bufB[U];
     if (cur.nchunk > 0) load(bufA, cur, 0);
 
     // ---- stage x into LDS, optionally as rmsnorm(x [+ add_r]) * ln_w ------------------
     const int kvec = a.k >> 3;
     if (a.prologue == kProNone) {
-        for (int c = threadIdx.x; c < M * kvec; c += kGT) {
+        for (int c = threadIdx.x; c < M * kvec; c += GT) {
             const int m = c / kvec, cv = c - m * kvec;
             st16(xs + m * a.k + cv * 8, ld16(a.x + (int64_t)m * a.ldx + cv * 8));
         }
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
             const int m = threadIdx.x >> 4, rr = threadIdx.x & 15;
             float s = 0.f;
 #pragma unroll
-            for (int w8 = 0; w8 < kGW; ++w8) s += red[(w8 * M + m) * 16 + rr];
+            for (int w8 = 0; w8 < GW; ++w8) s += red[(w8 * M + m) * 16 + rr];
             const int n = cur.nt * 16 + rr;
             if (a.ksplit > 1) {
                 a.partial[((int64_t)cur.ks * a.m + m) * a.n + n] = s;
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(kGT) void wgemm_dot_kernel(GemmArgs a) {
                 if (rr < 8) {
                     float g = 0.f;
 #pragma unroll
-                    for (int w8 = 0; w8 < kGW; ++w8) g += red[(w8 * M + m) * 16 + rr + 8];
+                    for (int w8 = 0; w8 < GW; ++w8) g += red[(w8 * M + m) * 16 + rr + 8];
                     reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + cur.nt * 8 + rr] =
                         (uint16_t)f32_to_bf16_bits(silu_mul_rounded(g, s));
                 }
@@ -447,13 +449,14 @@ static int pick_ksplit(int nt, int kt) {
     return best;
 }
 
-template <int M>
+template <int M, int GW>
 static int launch_dot(const GemmArgs& a, int grid, hipStream_t s) {
-    const size_t lds = (size_t)M * a.k * 2 + 16 + (size_t)kGW * M * 16 * 4;
+    constexpr int U = 4;
+    const size_t lds = (size_t)M * a.k * 2 + 16 + (size_t)GW * M * 16 * 4;
     if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
     static size_t configured = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgemm_dot_kernel<M>,
+        hipError_t e = hipFuncSetAttribute((const void*)wgemm_dot_kernel<M, GW, U>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_last_hip_error(e);
@@ -461,8 +464,13 @@ static int launch_dot(const GemmArgs& a, int grid, hipStream_t s) {
         }
         configured = 160 * 1024;
     }
-    hipLaunchKernelGGL(wgemm_dot_kernel<M>, dim3(grid), dim3(kGT), lds, s, a);
+    hipLaunchKernelGGL((wgemm_dot_kernel<M, GW, U>), dim3(grid), dim3(GW * kWave), lds, s, a);
     return check_launch();
+}
+
+template <int M>
+static int launch_dot_waves(const GemmArgs& a, int waves, int grid, hipStream_t s) {
+    return waves == 16 ? launch_dot<M, 16>(a, grid, s) : launch_dot<M, 8>(a, grid, s);
 }
 
 template <int MB>
@@ -534,10 +542,15 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     a.flags = flags;
 
     const int cus = num_cus();
-    // LDS of the dot form limits co-residency; never size the grid past what fits
-    int bpc = g_tune_bpc;
+    // Dot-form shape, from sweeps on MI355X (tools/sweep_wgemm.py, M=1, 4 tiles per stage):
+    // with at most one strip per CU a single 16-wave workgroup hides HBM latency best
+    // (O 8.0 -> 7.4 us, down 20.6 -> 20.4); with more strips than CUs two 8-wave workgroups
+    // per CU even out the tail (QKV 12.8 -> 11.3 us, gate/up 39.1 -> 37.6).
+    int waves = g_tune_waves ? g_tune_waves : (a.nunits <= cus ? 16 : 8);
+    int bpc = g_tune_bpc ? g_tune_bpc : (m <= 4 && waves == 8 ? 2 : 1);
     if (m <= 4) {
-        const size_t lds = (size_t)m * k * 2 + 16 + (size_t)kGW * m * 64;
+        // LDS limits co-residency; never size the grid past what fits
+        const size_t lds = (size_t)m * k * 2 + 16 + (size_t)waves * m * 64;
         const int fit = (int)((160 * 1024) / (lds + 512));
         if (fit < 1) return MV_ERR_UNSUPPORTED;
         if (bpc > fit) bpc = fit;
@@ -548,10 +561,10 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
 
     int rc;
     switch (m) {
-        case 1: rc = launch_dot<1>(a, grid, s); break;
-        case 2: rc = launch_dot<2>(a, grid, s); break;
-        case 3: rc = launch_dot<3>(a, grid, s); break;
-        case 4: rc = launch_dot<4>(a, grid, s); break;
+        case 1: rc = launch_dot_waves<1>(a, waves, grid, s); break;
+        case 2: rc = launch_dot_waves<2>(a, waves, grid, s); break;
+        case 3: rc = launch_dot_waves<3>(a, waves, grid, s); break;
+        case 4: rc = launch_dot_waves<4>(a, waves, grid, s); break;
         default: {
             const int mb = (m + 15) / 16;
             if (mb == 1) rc = launch_mfma<1>(a, grid, s);
@@ -575,9 +588,14 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
 
 extern "C" {
 
-// Tuning hook for experiments: key 0 = workgroups per CU, key 1 = forced ksplit (0 = auto).
+// Tuning hook for experiments: key 0 = workgroups per CU, key 1 = forced ksplit,
+// key 2 = waves per workgroup of the dot form (8 or 16); 0 = let the planner choose.
 int mv_wgemm_tune(int key, int value) {
-    if (key == 0 && value >= 1 && value <= 8) {
+    if (key == 2 && (value == 0 || value == 8 || value == 16)) {
+        mv::g_tune_waves = value;
+        return MV_OK;
+    }
+    if (key == 0 && value >= 0 && value <= 8) {
         mv::g_tune_bpc = value;
         return MV_OK;
     }

@@ -109,9 +109,14 @@ def test_wgemm_ksplit_variants_agree_and_are_deterministic(mv):
             assert nv.lib().mv_wgemm_tune(0, bpc) == 0
             y = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
             assert_close_bf16(y, want, atol=1e-3, rtol=2 ** -7)
+        for waves in (8, 16):
+            assert nv.lib().mv_wgemm_tune(2, waves) == 0
+            y = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
+            assert_close_bf16(y, want, atol=1e-3, rtol=2 ** -7)
     finally:
         nv.lib().mv_wgemm_tune(1, 0)
-        nv.lib().mv_wgemm_tune(0, 1)
+        nv.lib().mv_wgemm_tune(0, 0)
+        nv.lib().mv_wgemm_tune(2, 0)
 
 
 def test_wgemm_strided_rows_and_big_k(mv):

@@ -69,7 +69,7 @@ def main():
                 t = timed_graph(fn) / copies
                 print(f"  norm={int(norm)} ksplit={ks} bpc={bpc}: {t*1e6:8.2f} us  {nbytes/t/1e9:8.1f} GB/s", flush=True)
     L.mv_wgemm_tune(1, 0)
-    L.mv_wgemm_tune(0, 1)
+    L.mv_wgemm_tune(0, 0)
 
 
 if __name__ == "__main__":
