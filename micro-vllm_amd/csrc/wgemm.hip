@@ -83,8 +83,9 @@ struct UnitCtx {
     const uint4* wbase;
 };
 
-// GW waves per workgroup, each keeping two stages of U weight tiles in flight.
-template <int M, int GW, int U>
+// GW waves per workgroup, each keeping two stages of U weight tiles in flight; PRO = the
+// input transform (kProNone / kProNorm / kProAddNorm).
+template <int M, int GW, int U, int PRO>
 __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
     constexpr int GT = GW * kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -106,13 +107,14 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
         c.ntile = (kt1 - c.kt0 - wid + GW - 1) / GW;  // tiles of this wave (may be <= 0)
         c.nchunk = (c.ntile + U - 1) / U;
         c.last = max(c.ntile - 1, 0);
-        c.wbase = a.w + ((int64_t)c.nt * a.kt + c.kt0 + wid) * 64 + lane;
+        // a wave without tiles still issues (clamped) loads: point it at the slice's first tile
+        c.wbase = a.w + ((int64_t)c.nt * a.kt + c.kt0 + (c.ntile > 0 ? wid : 0)) * 64 + lane;
         return c;
     };
     auto load = [&](uint4(&buf)[U], const UnitCtx& c, int chunk) {
 #pragma unroll
         for (int i = 0; i < U; ++i) {
-            const int t = min(chunk * U + i, c.last);  // clamp: always a valid address
+            const int t = min(chunk * U + i, c.last);  // clamp: always a valid address (chunk < 2^24)
             buf[i] = ld16_nt(c.wbase + (int64_t)t * (GW * 64));
         }
     };
@@ -134,17 +136,70 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
         }
     };
 
-    // The weights do not depend on the previous kernel: get the first tiles moving before
-    // touching x, so their HBM latency overlaps the input transform below.
+    // Memory requests of a wave return in issue order, and two stages of weight tiles per wave
+    // are a couple of microseconds of HBM traffic: x (and the norm weight) are therefore
+    // requested FIRST, into registers, the weight stream is started behind them, and only
+    // then is x consumed.  Requested after the tiles, x would arrive behind them and the
+    // stream would stall until the input transform is through.
     int u = blockIdx.x;
     UnitCtx cur = setup(u);
     uint4 bufA[U], bufB[U];
-    if (cur.nchunk > 0) load(bufA, cur, 0);
+    const int kvec = a.k >> 3;
+
+    constexpr int kPT = 256;                              // threads of the input transform
+    constexpr int XC = 2;                                 // early chunks per thread, plain staging
+    constexpr int PC = (M == 1) ? 4 : (M == 2 ? 2 : 1);   // early chunks per thread and row, norm
+    // Straight-line code with clamped addresses (no branches around the loads), so the compiler
+    // can wait for exactly the x loads and leave the tile loads in flight.
+    uint4 xe[XC];
+    uint4 pxe[M][PC], pre[M][PC], pwe[PC];
+    if (PRO == kProNone) {
+#pragma unroll
+        for (int j = 0; j < XC; ++j) {
+            const int c = min((int)threadIdx.x + j * GT, M * kvec - 1);
+            const int m = c / kvec, cv = c - m * kvec;
+            xe[j] = ld16(a.x + (int64_t)m * a.ldx + cv * 8);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PC; ++j) {
+            if (j * kPT < kvec) {  // uniform
+                const int c = min((int)(threadIdx.x & (kPT - 1)) + j * kPT, kvec - 1);
+#pragma unroll
+                for (int m = 0; m < M; ++m) {
+                    pxe[m][j] = ld16(a.x + (int64_t)m * a.ldx + c * 8);
+                    if (PRO == kProAddNorm)
+                        pre[m][j] = ld16(a.add_r + (int64_t)m * a.ld_add_r + c * 8);
+                }
+                pwe[j] = ld16(a.ln_w + c * 8);
+            }
+        }
+    }
+    // Keep the issue order x, A0..A3 (B0..B3 follow the transform): the loop below waits by
+    // counting requests, and a first pass issued in any other order would make every later
+    // wait conservative.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+        const int t = min(i, cur.last);  // indices past the end are clamped to the wave's last tile
+        const uint4 v = ld16_nt(cur.wbase + (int64_t)t * (GW * 64));
+        bufA[i] = v;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("" ::: "memory");
 
     // ---- stage x into LDS, optionally as rmsnorm(x [+ add_r]) * ln_w ------------------
-    const int kvec = a.k >> 3;
-    if (a.prologue == kProNone) {
-        for (int c = threadIdx.x; c < M * kvec; c += GT) {
+    if (PRO == kProNone) {
+#pragma unroll
+        for (int j = 0; j < XC; ++j) {
+            const int c = threadIdx.x + j * GT;
+            if (c < M * kvec) {
+                const int m = c / kvec, cv = c - m * kvec;
+                st16(xs + m * a.k + cv * 8, xe[j]);
+            }
+        }
+        for (int c = threadIdx.x + XC * GT; c < M * kvec; c += GT) {
             const int m = c / kvec, cv = c - m * kvec;
             st16(xs + m * a.k + cv * 8, ld16(a.x + (int64_t)m * a.ldx + cv * 8));
         }
@@ -152,45 +207,53 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
     } else {
         // Same chunk assignment (256 threads, stride 256) and the same reduction order as the
         // stand-alone norm kernels, so fused and unfused paths agree bit for bit.
-        constexpr int kPT = 256;
         float ss[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) ss[m] = 0.f;
+        // one chunk of one row: (sum,) squares, LDS image, copy of the sum for the next block
+        auto absorb = [&](int m, int c, const uint4& xv, const uint4& rv) {
+            const uint32_t x4[4] = {xv.x, xv.y, xv.z, xv.w};
+            if (PRO == kProAddNorm) {
+                const uint32_t r4[4] = {rv.x, rv.y, rv.z, rv.w};
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float s0 = bf16_lo(x4[j]) + bf16_lo(r4[j]);
+                    float s1 = bf16_hi(x4[j]) + bf16_hi(r4[j]);
+                    o[j] = pack_bf16x2(s0, s1);
+                    if (a.var_from_rounded) {
+                        s0 = bf16_lo(o[j]);
+                        s1 = bf16_hi(o[j]);
+                    }
+                    ss[m] += s0 * s0;
+                    ss[m] += s1 * s1;
+                }
+                const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+                st16(xs + m * a.k + c * 8, ov);
+                if (blockIdx.x == 0) st16(a.sum_out + (int64_t)m * a.ld_sum_out + c * 8, ov);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v0 = bf16_lo(x4[j]), v1 = bf16_hi(x4[j]);
+                    ss[m] += v0 * v0;
+                    ss[m] += v1 * v1;
+                }
+                st16(xs + m * a.k + c * 8, xv);
+            }
+        };
         if (threadIdx.x < kPT) {
 #pragma unroll
             for (int m = 0; m < M; ++m) {
-                const uint16_t* xr = a.x + (int64_t)m * a.ldx;
-                for (int c = threadIdx.x; c < kvec; c += kPT) {
-                    const uint4 xv = ld16(xr + c * 8);
-                    const uint32_t x4[4] = {xv.x, xv.y, xv.z, xv.w};
-                    if (a.prologue == kProAddNorm) {
-                        const uint4 rv = ld16(a.add_r + (int64_t)m * a.ld_add_r + c * 8);
-                        const uint32_t r4[4] = {rv.x, rv.y, rv.z, rv.w};
-                        uint32_t o[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float s0 = bf16_lo(x4[j]) + bf16_lo(r4[j]);
-                            float s1 = bf16_hi(x4[j]) + bf16_hi(r4[j]);
-                            o[j] = pack_bf16x2(s0, s1);
-                            if (a.var_from_rounded) {
-                                s0 = bf16_lo(o[j]);
-                                s1 = bf16_hi(o[j]);
-                            }
-                            ss[m] += s0 * s0;
-                            ss[m] += s1 * s1;
-                        }
-                        const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
-                        st16(xs + m * a.k + c * 8, ov);
-                        if (blockIdx.x == 0) st16(a.sum_out + (int64_t)m * a.ld_sum_out + c * 8, ov);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v0 = bf16_lo(x4[j]), v1 = bf16_hi(x4[j]);
-                            ss[m] += v0 * v0;
-                            ss[m] += v1 * v1;
-                        }
-                        st16(xs + m * a.k + c * 8, xv);
-                    }
+                for (int j = 0; j < PC; ++j) {
+                    const int c = threadIdx.x + j * kPT;
+                    if (c < kvec) absorb(m, c, pxe[m][j], pre[m][j]);
+                }
+                for (int c = threadIdx.x + PC * kPT; c < kvec; c += kPT) {
+                    const uint4 xv = ld16(a.x + (int64_t)m * a.ldx + c * 8);
+                    uint4 rv = xv;
+                    if (PRO == kProAddNorm) rv = ld16(a.add_r + (int64_t)m * a.ld_add_r + c * 8);
+                    absorb(m, c, xv, rv);
                 }
             }
         }
@@ -209,44 +272,74 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
             for (int i = 0; i < kPT / 64; ++i) t += red[m * (kPT / 64) + i];
             rrms[m] = 1.0f / sqrtf(t / (float)a.k + a.eps);
         }
+        auto scale = [&](int m, int c, const uint4& wv) {
+            uint4* px = reinterpret_cast<uint4*>(xs + m * a.k + c * 8);
+            const uint4 sv = *px;
+            const uint32_t s4[4] = {sv.x, sv.y, sv.z, sv.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[j] = pack_bf16x2((bf16_lo(s4[j]) * rrms[m]) * bf16_lo(w4[j]),
+                                   (bf16_hi(s4[j]) * rrms[m]) * bf16_hi(w4[j]));
+            *px = make_uint4(o[0], o[1], o[2], o[3]);
+        };
         if (threadIdx.x < kPT) {
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                for (int c = threadIdx.x; c < kvec; c += kPT) {
-                    uint4* px = reinterpret_cast<uint4*>(xs + m * a.k + c * 8);
-                    const uint4 sv = *px, wv = ld16(a.ln_w + c * 8);
-                    const uint32_t s4[4] = {sv.x, sv.y, sv.z, sv.w}, w4[4] = {wv.x, wv.y, wv.z, wv.w};
-                    uint32_t o[4];
+            for (int j = 0; j < PC; ++j) {
+                const int c = threadIdx.x + j * kPT;
+                if (c < kvec) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        o[j] = pack_bf16x2((bf16_lo(s4[j]) * rrms[m]) * bf16_lo(w4[j]),
-                                           (bf16_hi(s4[j]) * rrms[m]) * bf16_hi(w4[j]));
-                    *px = make_uint4(o[0], o[1], o[2], o[3]);
+                    for (int m = 0; m < M; ++m) scale(m, c, pwe[j]);
                 }
+            }
+            for (int c = threadIdx.x + PC * kPT; c < kvec; c += kPT) {
+                const uint4 wv = ld16(a.ln_w + c * 8);
+#pragma unroll
+                for (int m = 0; m < M; ++m) scale(m, c, wv);
             }
         }
     }
     __syncthreads();
 
+    // Stage B goes out only now.  Requesting both stages before the input transform measured
+    // slower on MI355X for every decode projection (O: 8.0 vs 7.3 us).
+#pragma unroll
+    for (int i = U; i < 2 * U; ++i) {
+        const int t = min(i, cur.last);
+        bufB[i - U] = ld16_nt(cur.wbase + (int64_t)t * (GW * 64));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // Chunks 0 and 1 of the current unit are in flight in bufA / bufB here and at the top of
+    // every pass.  The stream is strictly A, B, A, B, ... with no branch around a load (a chunk
+    // index past the end re-reads the wave's last tile, a cache hit; its product is masked to
+    // zero), so every wait in the loop is for exactly one stage and the other stays in flight.
+    constexpr int kPast = 1 << 24;
     for (;;) {
+        const int un = u + gridDim.x;
+        const bool more = un < a.nunits;
+        UnitCtx nxt = cur;
+        if (more) nxt = setup(un);
+
         float acc[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[m] = 0.f;
 
-        for (int c = 0; c < cur.nchunk; c += 2) {  // chunk 0 is already in bufA
-            if (c + 1 < cur.nchunk) load(bufB, cur, c + 1);
-            compute(bufA, cur, c, acc);
-            if (c + 2 < cur.nchunk) load(bufA, cur, c + 2);
-            if (c + 1 < cur.nchunk) compute(bufB, cur, c + 1, acc);
+        const int npair = (cur.nchunk + 1) >> 1;
+        for (int p = 0; p < npair - 1; ++p) {
+            compute(bufA, cur, 2 * p, acc);
+            load(bufA, cur, 2 * p + 2);
+            compute(bufB, cur, 2 * p + 1, acc);
+            load(bufB, cur, 2 * p + 3);
         }
-
-        // next unit's first tiles go out before this unit's reduction
-        const int un = u + gridDim.x;
-        const bool more = un < a.nunits;
-        UnitCtx nxt = cur;
-        if (more) {
-            nxt = setup(un);
-            if (nxt.nchunk > 0) load(bufA, nxt, 0);
+        const int cl = npair > 0 ? 2 * (npair - 1) : kPast;  // nothing to add if the wave has no tiles
+        if (more) {  // two copies so that each path keeps exact request counts
+            compute(bufA, cur, cl, acc);
+            load(bufA, nxt, 0);
+            compute(bufB, cur, cl + 1, acc);
+            load(bufB, nxt, 1);
+        } else {
+            compute(bufA, cur, cl, acc);
+            compute(bufB, cur, cl + 1, acc);
         }
 
         // lanes r, r+16, r+32, r+48 hold the four k-quarters of row r
@@ -449,14 +542,14 @@ static int pick_ksplit(int nt, int kt) {
     return best;
 }
 
-template <int M, int GW>
+template <int M, int GW, int PRO>
 static int launch_dot(const GemmArgs& a, int grid, hipStream_t s) {
-    constexpr int U = 4;
+    constexpr int U = (M <= 2) ? 4 : 2;  // tiles per stage (register budget: 128 VGPRs at 16 waves per CU)
     const size_t lds = (size_t)M * a.k * 2 + 16 + (size_t)GW * M * 16 * 4;
     if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
     static size_t configured = 0;  // per instantiation
     if (lds > 64 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgemm_dot_kernel<M, GW, U>,
+        hipError_t e = hipFuncSetAttribute((const void*)wgemm_dot_kernel<M, GW, U, PRO>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) {
             set_last_hip_error(e);
@@ -464,13 +557,22 @@ static int launch_dot(const GemmArgs& a, int grid, hipStream_t s) {
         }
         configured = 160 * 1024;
     }
-    hipLaunchKernelGGL((wgemm_dot_kernel<M, GW, U>), dim3(grid), dim3(GW * kWave), lds, s, a);
+    hipLaunchKernelGGL((wgemm_dot_kernel<M, GW, U, PRO>), dim3(grid), dim3(GW * kWave), lds, s, a);
     return check_launch();
+}
+
+template <int M, int GW>
+static int launch_dot_pro(const GemmArgs& a, int grid, hipStream_t s) {
+    switch (a.prologue) {
+        case kProNone: return launch_dot<M, GW, kProNone>(a, grid, s);
+        case kProNorm: return launch_dot<M, GW, kProNorm>(a, grid, s);
+        default: return launch_dot<M, GW, kProAddNorm>(a, grid, s);
+    }
 }
 
 template <int M>
 static int launch_dot_waves(const GemmArgs& a, int waves, int grid, hipStream_t s) {
-    return waves == 16 ? launch_dot<M, 16>(a, grid, s) : launch_dot<M, 8>(a, grid, s);
+    return waves == 16 ? launch_dot_pro<M, 16>(a, grid, s) : launch_dot_pro<M, 8>(a, grid, s);
 }
 
 template <int MB>
