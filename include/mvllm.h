@@ -126,6 +126,15 @@ int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_
  * key 2 = waves per workgroup of the M <= 4 kernel (8 or 16; 0 = planner). */
 int mv_wgemm_tune(int key, int value);
 
+/* y[M,N] = x[M,K] . W^T for many rows (prefill) on the matrix cores, reading the same tile image
+ * as mv_wgemm (mv_shuffle_weight / mv_interleave_rows8); flags, bias, residual, rounding and the
+ * SWIGLU output width as for mv_wgemm.  K must be a multiple of 64, N of 16; any M >= 0.
+ * Replaces torch.matmul at core/layer/model_prefill.py:42,54, the compiled _mlp (:58,
+ * core/layer/model_graph.py:75-81) and lm_head (:62). */
+int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
+                    const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,
+                    int k, int flags, mv_stream_t stream);
+
 /* ---------------------------------------------------- paged attention */
 
 /* Bytes of fp32 workspace for split-KV partial results. */

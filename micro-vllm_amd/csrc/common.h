@@ -38,6 +38,14 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
                                            __builtin_bit_cast(bf16x2_t, b), acc, false);
 }
 
+// SwiGLU on two projection accumulators: both are rounded to bf16 first (the reference
+// materialises gate_up in bf16, kernel/swiglu.py:35-45), the product is formed in fp32.
+__device__ __forceinline__ float silu_mul_rounded(float gate_acc, float up_acc) {
+    const float g = round_bf16(gate_acc), u = round_bf16(up_acc);
+    const float sig = 1.0f / (1.0f + expf(-g));
+    return (g * sig) * u;
+}
+
 // ---- cross-lane ----------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

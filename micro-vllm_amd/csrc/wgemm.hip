@@ -63,12 +63,6 @@ struct GemmArgs {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
-__device__ __forceinline__ float silu_mul_rounded(float gate_acc, float up_acc) {
-    const float g = round_bf16(gate_acc), u = round_bf16(up_acc);
-    const float sig = 1.0f / (1.0f + expf(-g));
-    return (g * sig) * u;
-}
-
 // Final value of one output element from its fp32 accumulator.
 __device__ __forceinline__ float epilogue_value(const GemmArgs& a, float acc, int m, int n) {
     float t = round_bf16(acc);

@@ -113,6 +113,37 @@ def wgemm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
     return out
 
 
+def gemm_prefill(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
+                 bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+                 swiglu: bool = False) -> torch.Tensor:
+    """Same contract as `wgemm` for any number of rows, on the matrix cores (the prefill
+    runner's torch.matmul calls, core/layer/model_prefill.py:42,54,58,62)."""
+    assert x.is_cuda and out.is_cuda and x.dtype == torch.bfloat16
+    assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
+    m, k = x.shape
+    assert k == w.k, f"K mismatch: {k} vs {w.k}"
+    assert swiglu == w.swiglu, "weight layout and epilogue disagree"
+    ncols = w.out_features
+    assert out.shape == (m, ncols), f"Output shape mismatch: {tuple(out.shape)} vs {(m, ncols)}"
+    flags = nv.MV_GEMM_SWIGLU if swiglu else nv.MV_GEMM_DEFAULT
+    if out.dtype == torch.float32:
+        flags |= nv.MV_GEMM_OUT_F32
+    else:
+        assert out.dtype == torch.bfloat16
+    if bias is not None:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == w.n and bias.is_contiguous()
+    ld_res = 0
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape == (m, w.n) and residual.stride(1) == 1
+        ld_res = residual.stride(0) if m > 1 else w.n
+    ldx = x.stride(0) if m > 1 else max(k, x.stride(0))
+    ldy = out.stride(0) if m > 1 else max(ncols, out.stride(0))
+    nv.check("mv_gemm_prefill", nv.lib().mv_gemm_prefill(
+        x.data_ptr(), ldx, w.tiles.data_ptr(), nv.ptr(bias), nv.ptr(residual), ld_res,
+        out.data_ptr(), ldy, m, w.n, k, flags, nv.stream_ptr()))
+    return out
+
+
 def wgemm_norm(x: torch.Tensor, ln_weight: torch.Tensor, eps: float, w: StreamedWeight,
                out: torch.Tensor, add_r: Optional[torch.Tensor] = None,
                sum_out: Optional[torch.Tensor] = None, var_from_rounded: bool = False,

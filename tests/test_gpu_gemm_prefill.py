@@ -1,0 +1,94 @@
+"""Many-row MFMA projection (mv_gemm_prefill) against the CPU oracle's linear_ref / swiglu_ref and
+against the single-token kernel on the same tile image."""
+import pytest
+import torch
+
+from conftest import assert_close_bf16, ulp_diff
+from oracle.ref_ops import linear_ref, swiglu_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _mk(m, n, k, seed, scale=0.05):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) * scale).to(torch.bfloat16)
+    return x, w, g
+
+
+# ragged M (partial m-blocks), N that is not a multiple of the 256-column block, one k stage
+@pytest.mark.parametrize("m", [1, 16, 127, 128, 129, 300, 1024])
+@pytest.mark.parametrize("n,k", [(64, 64), (272, 2048), (4096, 1024), (2560, 2048)])
+def test_gemm_prefill_vs_oracle(mv, m, n, k):
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    x, w, _ = _mk(m, n, k, seed=m + 3 * n + k)
+    sw = StreamedWeight.from_linear(w.to(DEV))
+    acc = gemm_prefill(x.to(DEV), sw, torch.empty(m, n, dtype=torch.float32, device=DEV))
+    want32 = x.float() @ w.float().t()
+    scale = max(1.0, want32.abs().max().item())
+    assert (acc.cpu() - want32).abs().max().item() <= 1e-4 * scale
+    y = gemm_prefill(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
+    want = linear_ref(x, w)
+    assert_close_bf16(y, want, atol=1e-4 * scale, rtol=2 ** -7, what=f"gemm_prefill m={m} n={n} k={k}")
+    assert float((ulp_diff(y, want) == 0).float().mean()) > 0.99
+
+
+def test_gemm_prefill_epilogues(mv):
+    """bias and residual rounding points, strided rows, fused SwiGLU (rows interleaved by 8)."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    m, n, k = 200, 512, 1024
+    x, w, g = _mk(m, n, k, seed=5)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16)
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16)
+    sw = StreamedWeight.from_linear(w.to(DEV))
+    xb = torch.zeros(m, k + 64, dtype=torch.bfloat16, device=DEV)
+    xb[:, :k] = x.to(DEV)
+    yb = torch.full((m, n + 32), 7.0, dtype=torch.bfloat16, device=DEV)
+    gemm_prefill(xb[:, :k], sw, yb[:, :n], bias=bias.to(DEV), residual=res.to(DEV))
+    t = linear_ref(x, w, bias)
+    want = (t.float() + res.float()).to(torch.bfloat16)
+    # a one-ulp flip of an intermediate survives the cancellation in t + res: allow one ulp
+    # of the larger operand
+    err = (yb[:, :n].cpu().float() - want.float()).abs()
+    tol = 1e-3 + 2 ** -7 * torch.maximum(t.float().abs(), want.float().abs())
+    assert bool((err <= tol).all()), f"bias+residual: max err {err.max().item():.3e}"
+    assert float((ulp_diff(yb[:, :n], want) == 0).float().mean()) > 0.99
+    assert torch.all(yb[:, n:] == 7.0), "wrote past the row"
+
+    inter = 768
+    up = (torch.randn(inter, k, generator=g) * 0.05).to(torch.bfloat16)
+    gate = (torch.randn(inter, k, generator=g) * 0.05).to(torch.bfloat16)
+    gu = StreamedWeight.from_up_gate(up.to(DEV), gate.to(DEV))
+    act = gemm_prefill(x.to(DEV), gu, torch.empty(m, inter, dtype=torch.bfloat16, device=DEV), swiglu=True)
+    want = swiglu_ref(linear_ref(x, torch.cat([up, gate], 0)))
+    # gate and up may each sit on a rounding boundary (one bf16 ulp apart between two fp32
+    # summation orders); the product then moves by up to two ulps
+    assert_close_bf16(act, want, atol=1e-3, rtol=2 ** -6, what="fused swiglu")
+    assert float((ulp_diff(act, want) == 0).float().mean()) > 0.98
+
+
+def test_gemm_prefill_agrees_with_single_token_kernel(mv):
+    """Same weights, same rows: the two kernels differ only in fp32 summation order."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill, wgemm
+
+    m, n, k = 48, 1024, 4096
+    x, w, _ = _mk(m, n, k, seed=9, scale=0.02)
+    sw = StreamedWeight.from_linear(w.to(DEV))
+    a = gemm_prefill(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
+    b = wgemm(x.to(DEV), sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV))
+    assert_close_bf16(a, b.cpu(), atol=1e-4 * max(1.0, float(b.float().abs().max())), rtol=2 ** -7,
+                      what="prefill vs single-token kernel")
+    assert float((ulp_diff(a, b) == 0).float().mean()) > 0.99
+
+
+def test_gemm_prefill_rejects_bad_shapes(mv):
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    w = StreamedWeight.from_linear(torch.zeros(64, 96, dtype=torch.bfloat16, device=DEV))
+    x = torch.zeros(4, 96, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(AssertionError):  # K = 96 is not a multiple of 64
+        gemm_prefill(x, w, torch.empty(4, 64, dtype=torch.bfloat16, device=DEV))
+    assert gemm_prefill(x[:0], w, torch.empty(0, 64, dtype=torch.bfloat16, device=DEV)).shape == (0, 64)
