@@ -169,6 +169,38 @@ int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, c
                          size_t workspace_bytes, int bs, int hq, int hkv, int d, int page,
                          int num_pages, float scale, int num_splits, mv_stream_t stream);
 
+/* ---- prefill (many tokens per sequence) ---- */
+
+/* NeoX rotation of `heads` heads of width d per row, y may alias x; row t uses cos/sin[t % seq].
+ * Evaluated like the reference's bf16 tensor expression (every product and the sum/difference
+ * round to bf16): core/layer/rope.py:10-39 (half-width table branch :28-33). */
+int mv_rope_prefill(const void* x, int64_t x_stride, void* y, int64_t y_stride, const void* rot_cos,
+                    const void* rot_sin, int rot_max_pos, int64_t tokens, int seq, int heads, int d,
+                    mv_stream_t stream);
+
+/* One launch for what the prefill runner does between the QKV projection and attention
+ * (core/layer/model_prefill.py:45-52): rows of qkv are [q heads | k heads | v heads]; token i of
+ * sequence b sits at position p = cache_seqlens[b] + i; q and k are rotated in place with
+ * cos/sin[p] (mv_rope_prefill arithmetic; skipped when cos == NULL) and the rotated k and v are
+ * written to k_cache/v_cache[block_table[b, p / page], p % page, h, :]. */
+int mv_rope_store_prefill(void* qkv, int64_t row_stride, const void* rot_cos, const void* rot_sin,
+                          int rot_max_pos, const int32_t* cache_seqlens, const int32_t* block_table,
+                          int bt_stride, void* k_cache, void* v_cache, int bs, int seq, int hq,
+                          int hkv, int d, int page, int num_pages, mv_stream_t stream);
+
+/* Causal attention of `seq` new tokens per sequence over the paged cache, which must already
+ * hold their keys and values (mv_rope_store_prefill / mv_store_kv): query i of sequence b sees
+ * keys 0 .. cache_seqlens[b] + i (bottom-right aligned mask), q head h reads kv head h / (Hq/Hkv).
+ * q rows: [bs*seq][q_stride] with heads contiguous; out rows likewise.  fp32 scores and softmax,
+ * P rounded to bf16 as the matrix-core operand, fp32 accumulation, bf16 output.
+ * D in {64,128}; Hq/Hkv in {1,2,4,8}; page a power of two >= 64.
+ * With the store above this replaces flash_attn_with_kvcache(q, k_cache, v_cache, k=, v=,
+ * cache_seqlens=, block_table=, causal=True) at core/layer/model_prefill.py:49-52. */
+int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                          const int32_t* cache_seqlens, const int32_t* block_table, int bt_stride,
+                          void* out, int64_t out_stride, int bs, int seq, int hq, int hkv, int d,
+                          int page, int num_pages, float scale, mv_stream_t stream);
+
 /* key[t,h,:] -> k_cache[slot/page, slot%page, h, :] (same for value); slot -1 = skip.
  * key/value: [T,H,D] with token stride kv_stride_t; slot_mapping int32 [T].
  * Replaces core/cache_manager.py:143 store_kvcache (Triton store_kvcache_kernel :75). */

@@ -121,6 +121,8 @@ class ModelGraphRunner:
         g_kv = getattr(cfg, "num_key_value_heads", g_heads)
         dev = self.device
         for block in self.model.transformer.h:
+            if isinstance(getattr(block.attn, "_qkv_w", None), StreamedWeight):
+                continue  # another runner on this model (decode + prefill) already did the relayout
             sh = shard_block_weights(block, g_heads, g_kv, self.head_size, self.rank, self.world_size)
             up, gate = sh["up"].to(dev), sh["gate"].to(dev)
             if self.fused:
@@ -140,9 +142,13 @@ class ModelGraphRunner:
         tr.wte.weight = tr.wte.weight.to(dev).contiguous()
         tr.ln_f.weight = tr.ln_f.weight.to(dev)
         # embedding, final norm and LM head are replicated on every rank (model_graph.py:196,222-223)
-        self._lm_head = StreamedWeight.from_linear(self.model.lm_head.weight.to(dev))
-        if self.release_source_weights:
-            self.model.lm_head.weight = None
+        shared = getattr(self.model, "_mv_lm_head_tiles", None)
+        if shared is None:
+            shared = StreamedWeight.from_linear(self.model.lm_head.weight.to(dev))
+            self.model._mv_lm_head_tiles = shared
+            if self.release_source_weights:
+                self.model.lm_head.weight = None
+        self._lm_head = shared
         torch.cuda.synchronize()
         logger.info("weights relaid out (rank %d)", self.rank)
 

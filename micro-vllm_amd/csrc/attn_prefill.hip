@@ -1,0 +1,449 @@
+// Prefill attention over the paged KV cache: a rotate-and-store kernel that appends the
+// chunk's keys and values to their pages, and a causal flash-attention kernel on the matrix
+// cores that reads keys and values back through the block table.
+//
+// Attention kernel.  Workgroup = (sequence, kv head, block of 128/G query positions): the G
+// query heads that share the kv head are stacked into 128 rows, so every K/V tile staged in
+// LDS serves all of them.  Wave w owns rows 32w..32w+31 as two 16-row tiles.
+//   S^T = K . Q^T   v_mfma_f32_16x16x32_bf16, A = K rows from LDS (ds_read_b128), B = Q from
+//                   registers; a lane holds 4 keys x 1 query per tile, so a query's running
+//                   max and sum live in one lane column (reduced over lanes l, l^16, l^32).
+//   O^T = V^T . P^T the two S^T tiles of a 32-key step, rounded to bf16, ARE the B operand
+//                   (keys in the order 4q..4q+3, 16+4q..16+4q+3 for lane group q); V^T comes
+//                   from the row-major V tile with the transposing LDS read
+//                   (ds_read_b64_tr_b16), which delivers those same keys.
+// Softmax in fp32 with exp2 and a folded scale; the normaliser sums the unrounded P; P is
+// rounded to bf16 as the matrix operand (as in the flash-attn package this call stands for).
+// K/V tiles of 64 keys are staged twice buffered; key positions past the last valid key are
+// clamped on load (finite data, masked to zero weight).
+#include "common.h"
+
+namespace mv {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+constexpr float kPfNegBig = -1.0e30f;
+
+// ------------------------------------------------------------------ rotate + store
+struct RopeStoreArgs {
+    uint16_t* qkv;          // [B*S][row_stride]: q heads | k heads | v heads
+    int64_t row_stride;
+    const uint16_t* cos;    // [max_pos][D/2] or null
+    const uint16_t* sin;
+    int rot_max_pos;
+    const int32_t* start;   // [B] tokens already cached
+    const int32_t* block_table;
+    int bt_stride;
+    uint16_t* k_cache;
+    uint16_t* v_cache;
+    int B, S, hq, hkv, d;
+    int page, page_shift, num_pages;
+};
+
+// bf16 tensor arithmetic of core/layer/rope.py:29-33: every product and the sum round to bf16
+__device__ __forceinline__ void rope_pair(uint32_t x1, uint32_t x2, uint32_t c, uint32_t s,
+                                          uint32_t& o1, uint32_t& o2) {
+    const float a_lo = round_bf16(bf16_lo(x1) * bf16_lo(c)), a_hi = round_bf16(bf16_hi(x1) * bf16_hi(c));
+    const float b_lo = round_bf16(bf16_lo(x2) * bf16_lo(s)), b_hi = round_bf16(bf16_hi(x2) * bf16_hi(s));
+    const float c_lo = round_bf16(bf16_lo(x2) * bf16_lo(c)), c_hi = round_bf16(bf16_hi(x2) * bf16_hi(c));
+    const float d_lo = round_bf16(bf16_lo(x1) * bf16_lo(s)), d_hi = round_bf16(bf16_hi(x1) * bf16_hi(s));
+    o1 = pack_bf16x2(a_lo - b_lo, a_hi - b_hi);
+    o2 = pack_bf16x2(c_lo + d_lo, c_hi + d_hi);
+}
+
+// one thread = one 16-byte chunk pair (first half / second half) of one head of one token
+__global__ __launch_bounds__(256) void rope_store_kernel(RopeStoreArgs a) {
+    const int cph = a.d >> 4;                       // chunk pairs per head
+    const int heads = a.hq + 2 * a.hkv;
+    const int64_t total = (int64_t)a.B * a.S * heads * cph;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % cph);
+        const int h = (int)((idx / cph) % heads);
+        const int64_t tok = idx / ((int64_t)cph * heads);
+        const int b = (int)(tok / a.S), i = (int)(tok - (int64_t)b * a.S);
+        const int pos = a.start[b] + i;
+        uint16_t* base = a.qkv + tok * a.row_stride + (int64_t)h * a.d;
+        uint4 v1 = ld16(base + c * 8), v2 = ld16(base + (a.d >> 1) + c * 8);
+        if (h < a.hq + a.hkv && a.cos) {
+            const int rp = min(pos, a.rot_max_pos - 1);
+            const uint4 cv = ld16(a.cos + (int64_t)rp * (a.d >> 1) + c * 8);
+            const uint4 sv = ld16(a.sin + (int64_t)rp * (a.d >> 1) + c * 8);
+            rope_pair(v1.x, v2.x, cv.x, sv.x, v1.x, v2.x);
+            rope_pair(v1.y, v2.y, cv.y, sv.y, v1.y, v2.y);
+            rope_pair(v1.z, v2.z, cv.z, sv.z, v1.z, v2.z);
+            rope_pair(v1.w, v2.w, cv.w, sv.w, v1.w, v2.w);
+            st16(base + c * 8, v1);
+            st16(base + (a.d >> 1) + c * 8, v2);
+        }
+        if (h >= a.hq) {
+            const int pg = a.block_table[(int64_t)b * a.bt_stride + (pos >> a.page_shift)];
+            if (pg < 0 || pg >= a.num_pages) continue;  // unallocated: nothing to write to
+            const bool is_v = h >= a.hq + a.hkv;
+            const int kvh = h - a.hq - (is_v ? a.hkv : 0);
+            uint16_t* dst = (is_v ? a.v_cache : a.k_cache) +
+                            (((int64_t)pg * a.page + (pos & (a.page - 1))) * a.hkv + kvh) * a.d;
+            st16(dst + c * 8, v1);
+            st16(dst + (a.d >> 1) + c * 8, v2);
+        }
+    }
+}
+
+// RoPE alone on [tokens][heads*d] rows (position = token index inside its sequence)
+__global__ __launch_bounds__(256) void rope_rows_kernel(const uint16_t* x, int64_t x_stride, uint16_t* y,
+                                                        int64_t y_stride, const uint16_t* cos,
+                                                        const uint16_t* sin, int rot_max_pos,
+                                                        int64_t tokens, int seq, int heads, int d) {
+    const int cph = d >> 4;
+    const int64_t total = tokens * heads * cph;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * 256) {
+        const int c = (int)(idx % cph);
+        const int h = (int)((idx / cph) % heads);
+        const int64_t tok = idx / ((int64_t)cph * heads);
+        const int pos = min((int)(tok % seq), rot_max_pos - 1);
+        const uint16_t* src = x + tok * x_stride + (int64_t)h * d;
+        uint16_t* dst = y + tok * y_stride + (int64_t)h * d;
+        uint4 v1 = ld16(src + c * 8), v2 = ld16(src + (d >> 1) + c * 8);
+        const uint4 cv = ld16(cos + (int64_t)pos * (d >> 1) + c * 8);
+        const uint4 sv = ld16(sin + (int64_t)pos * (d >> 1) + c * 8);
+        rope_pair(v1.x, v2.x, cv.x, sv.x, v1.x, v2.x);
+        rope_pair(v1.y, v2.y, cv.y, sv.y, v1.y, v2.y);
+        rope_pair(v1.z, v2.z, cv.z, sv.z, v1.z, v2.z);
+        rope_pair(v1.w, v2.w, cv.w, sv.w, v1.w, v2.w);
+        st16(dst + c * 8, v1);
+        st16(dst + (d >> 1) + c * 8, v2);
+    }
+}
+
+// ------------------------------------------------------------------ attention
+struct PfArgs {
+    const uint16_t* q;      // [B*S][q_stride] rows, heads contiguous
+    int64_t q_stride;
+    const uint16_t* k_cache;
+    const uint16_t* v_cache;
+    const int32_t* start;
+    const int32_t* block_table;
+    int bt_stride;
+    uint16_t* out;          // [B*S][out_stride]
+    int64_t out_stride;
+    int B, S, hq, hkv, g;
+    int qt, qt_shift;       // query positions per workgroup = 128 / g
+    int nqb;
+    int page_shift, num_pages, page;
+    float scale_log2;
+};
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
+    constexpr int KT = 64;             // keys per LDS tile
+    constexpr int KS = D / 32;         // k-steps of K.Q^T
+    constexpr int DT = D / 16;         // 16-wide slices of the head dimension
+    constexpr int KROW = D * 2 + 16;   // LDS row strides (bytes): conflict-free row reads ...
+    constexpr int VROW = D * 2 + 32;   // ... and conflict-free transposed reads
+    constexpr int VPR = D / 8;         // 16-byte vectors per row
+    constexpr int NV = KT * VPR / 256; // vectors per thread per tile
+    __shared__ __attribute__((aligned(16))) unsigned char kL[2][KT * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned char vL[2][KT * VROW];
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+
+    // heaviest query blocks (most keys) first
+    const int per = a.hkv * a.B;
+    const int qb = a.nqb - 1 - (int)(blockIdx.x / per);
+    const int rem = blockIdx.x % per;
+    const int kvh = rem % a.hkv, b = rem / a.hkv;
+    const int p0 = a.start[b];
+    const int i0 = qb * a.qt;
+    const int last_key = p0 + min(i0 + a.qt, a.S) - 1;   // last key any row of this block sees
+    const int ntiles = last_key / KT + 1;
+    const int32_t* bt = a.block_table + (int64_t)b * a.bt_stride;
+
+    // this lane's query rows (C-layout column r of each of the wave's two tiles)
+    int limit[2], qi[2], head[2];
+    bf16x8_t qf[2][KS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = wid * 32 + mt * 16 + r;
+        const int gi = row >> a.qt_shift, i = i0 + (row & (a.qt - 1));
+        head[mt] = kvh * a.g + gi;
+        qi[mt] = i;
+        const int ic = min(i, a.S - 1);
+        limit[mt] = p0 + ic;
+        const uint16_t* qp = a.q + ((int64_t)b * a.S + ic) * a.q_stride + (int64_t)head[mt] * D + q * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+            qf[mt][ks] = __builtin_bit_cast(bf16x8_t, ld16(qp + ks * 32));
+    }
+
+    // K/V staging: thread moves vectors t + 256 j of the 64 x VPR tile
+    auto tile_page = [&](int t) {
+        const int pg = bt[(t * KT) >> a.page_shift];
+        return (pg >= 0 && pg < a.num_pages) ? pg : 0;   // contract breach: stay inside the cache
+    };
+    auto g_load = [&](uint4(&kr)[NV], uint4(&vr)[NV], int t, int pg) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = threadIdx.x + 256 * j, row = v / VPR, ch = v % VPR;
+            const int kp = min(t * KT + row, last_key);
+            const int64_t off = (((int64_t)pg * a.page + (kp & (a.page - 1))) * a.hkv + kvh) * D + ch * 8;
+            kr[j] = ld16(a.k_cache + off);
+            vr[j] = ld16(a.v_cache + off);
+        }
+    };
+    auto l_store = [&](const uint4(&kr)[NV], const uint4(&vr)[NV], int buf) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int v = threadIdx.x + 256 * j, row = v / VPR, ch = v % VPR;
+            *reinterpret_cast<uint4*>(&kL[buf][row * KROW + ch * 16]) = kr[j];
+            *reinterpret_cast<uint4*>(&vL[buf][row * VROW + ch * 16]) = vr[j];
+        }
+    };
+
+    f32x4_t oacc[2][DT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[mt][dt] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    float mrun[2] = {kPfNegBig, kPfNegBig}, lrun[2] = {0.f, 0.f};
+
+    uint4 kr[NV], vr[NV];
+    int pg_next = tile_page(0);
+    g_load(kr, vr, 0, pg_next);
+    pg_next = ntiles > 1 ? tile_page(1) : 0;
+    l_store(kr, vr, 0);
+    __syncthreads();
+
+    // transposed-read lane address inside a 16-key x 16-column block pair
+    const int li = lane & 15;
+    const int tr_off = (4 * q + (li >> 2)) * VROW + (li & 3) * 8;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const bool more = t + 1 < ntiles;
+        if (more) {
+            g_load(kr, vr, t + 1, pg_next);
+            if (t + 2 < ntiles) pg_next = tile_page(t + 2);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {   // 32-key steps
+            const int kb = t * KT + h * 32;
+            if (kb > last_key) break;   // uniform
+            f32x4_t sacc[2][2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int x = 0; x < 2; ++x) sacc[mt][x] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int x = 0; x < 2; ++x) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const bf16x8_t kf = __builtin_bit_cast(
+                        bf16x8_t, *reinterpret_cast<const uint4*>(
+                                      &kL[buf][(h * 32 + x * 16 + r) * KROW + ks * 64 + q * 16]));
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        sacc[mt][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mt][ks], sacc[mt][x], 0, 0, 0);
+                }
+            }
+            bf16x8_t pf[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                float s[8];
+                float mloc = kPfNegBig;
+#pragma unroll
+                for (int x = 0; x < 2; ++x)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int key = kb + x * 16 + q * 4 + j;
+                        const float v = (key <= limit[mt]) ? sacc[mt][x][j] * a.scale_log2 : kPfNegBig;
+                        s[x * 4 + j] = v;
+                        mloc = fmaxf(mloc, v);
+                    }
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+                const float mnew = fmaxf(mrun[mt], mloc);
+                const float alpha = exp2f(mrun[mt] - mnew);
+                mrun[mt] = mnew;
+                float psum = 0.f;
+                float p[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    p[e] = exp2f(s[e] - mnew);
+                    psum += p[e];
+                }
+                lrun[mt] = lrun[mt] * alpha + psum;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) oacc[mt][dt] *= alpha;
+                uint4 pk;
+                pk.x = pack_bf16x2(p[0], p[1]);
+                pk.y = pack_bf16x2(p[2], p[3]);
+                pk.z = pack_bf16x2(p[4], p[5]);
+                pk.w = pack_bf16x2(p[6], p[7]);
+                pf[mt] = __builtin_bit_cast(bf16x8_t, pk);
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const unsigned char* vb = &vL[buf][h * 32 * VROW + dt * 32 + tr_off];
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4_t __attribute__((address_space(3)))*)(vb));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (s16x4_t __attribute__((address_space(3)))*)(vb + 16 * VROW));
+                typedef __attribute__((ext_vector_type(8))) short s16x8;
+                const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, both);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    oacc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mt], oacc[mt][dt], 0, 0, 0);
+            }
+        }
+        if (more) l_store(kr, vr, buf ^ 1);
+        __syncthreads();
+    }
+
+    // oacc[mt][dt][j] = O^T[d = 16 dt + 4q + j][query row r]
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float l = lrun[mt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        if (qi[mt] < a.S) {
+            uint16_t* op = a.out + ((int64_t)b * a.S + qi[mt]) * a.out_stride + (int64_t)head[mt] * D + q * 4;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const f32x4_t o = oacc[mt][dt];
+                uint2 w;
+                w.x = pack_bf16x2(o[0] * inv, o[1] * inv);
+                w.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+                *reinterpret_cast<uint2*>(op + dt * 16) = w;
+            }
+        }
+    }
+}
+
+}  // namespace mv
+
+extern "C" {
+
+int mv_rope_store_prefill(void* qkv, int64_t row_stride, const void* rot_cos, const void* rot_sin,
+                          int rot_max_pos, const int32_t* cache_seqlens, const int32_t* block_table,
+                          int bt_stride, void* k_cache, void* v_cache, int bs, int seq, int hq,
+                          int hkv, int d, int page, int num_pages, mv_stream_t stream) {
+    using namespace mv;
+    if (bs == 0 || seq == 0) return MV_OK;
+    if (!qkv || !cache_seqlens || !block_table || !k_cache || !v_cache) return MV_ERR_INVALID_ARG;
+    if (bs < 0 || seq < 0 || hq <= 0 || hkv <= 0 || page <= 0 || num_pages <= 0 || bt_stride <= 0)
+        return MV_ERR_INVALID_ARG;
+    if ((rot_cos == nullptr) != (rot_sin == nullptr)) return MV_ERR_INVALID_ARG;
+    if (rot_cos && rot_max_pos <= 0) return MV_ERR_INVALID_ARG;
+    if ((d % 16) != 0 || d > 256) return MV_ERR_UNSUPPORTED;
+    if (page & (page - 1)) return MV_ERR_UNSUPPORTED;
+    if (!aligned16(qkv) || (row_stride % 8) != 0 || row_stride < (int64_t)(hq + 2 * hkv) * d ||
+        !aligned16(k_cache) || !aligned16(v_cache))
+        return MV_ERR_INVALID_ARG;
+    if (rot_cos && (!aligned16(rot_cos) || !aligned16(rot_sin))) return MV_ERR_INVALID_ARG;
+    RopeStoreArgs a;
+    a.qkv = (uint16_t*)qkv;
+    a.row_stride = row_stride;
+    a.cos = (const uint16_t*)rot_cos;
+    a.sin = (const uint16_t*)rot_sin;
+    a.rot_max_pos = rot_max_pos;
+    a.start = cache_seqlens;
+    a.block_table = block_table;
+    a.bt_stride = bt_stride;
+    a.k_cache = (uint16_t*)k_cache;
+    a.v_cache = (uint16_t*)v_cache;
+    a.B = bs;
+    a.S = seq;
+    a.hq = hq;
+    a.hkv = hkv;
+    a.d = d;
+    a.page = page;
+    a.page_shift = __builtin_ctz((unsigned)page);
+    a.num_pages = num_pages;
+    const int64_t total = (int64_t)bs * seq * (hq + 2 * hkv) * (d / 16);
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rope_store_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+int mv_rope_prefill(const void* x, int64_t x_stride, void* y, int64_t y_stride, const void* rot_cos,
+                    const void* rot_sin, int rot_max_pos, int64_t tokens, int seq, int heads, int d,
+                    mv_stream_t stream) {
+    using namespace mv;
+    if (tokens == 0) return MV_OK;
+    if (!x || !y || !rot_cos || !rot_sin || tokens < 0 || seq <= 0 || heads <= 0 || rot_max_pos <= 0)
+        return MV_ERR_INVALID_ARG;
+    if ((d % 16) != 0 || d > 256) return MV_ERR_UNSUPPORTED;
+    if (!aligned16(x) || !aligned16(y) || !aligned16(rot_cos) || !aligned16(rot_sin) ||
+        (x_stride % 8) != 0 || (y_stride % 8) != 0 || x_stride < (int64_t)heads * d ||
+        y_stride < (int64_t)heads * d)
+        return MV_ERR_INVALID_ARG;
+    const int64_t total = tokens * heads * (d / 16);
+    int64_t blocks = (total + 255) / 256;
+    const int64_t cap = (int64_t)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(rope_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)x, x_stride, (uint16_t*)y, y_stride, (const uint16_t*)rot_cos,
+                       (const uint16_t*)rot_sin, rot_max_pos, tokens, seq, heads, d);
+    return check_launch();
+}
+
+int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
+                          const int32_t* cache_seqlens, const int32_t* block_table, int bt_stride,
+                          void* out, int64_t out_stride, int bs, int seq, int hq, int hkv, int d,
+                          int page, int num_pages, float scale, mv_stream_t stream) {
+    using namespace mv;
+    if (bs == 0 || seq == 0) return MV_OK;
+    if (!q || !k_cache || !v_cache || !cache_seqlens || !block_table || !out) return MV_ERR_INVALID_ARG;
+    if (bs < 0 || seq < 0 || hq <= 0 || hkv <= 0 || page <= 0 || num_pages <= 0 || bt_stride <= 0)
+        return MV_ERR_INVALID_ARG;
+    if (d != 64 && d != 128) return MV_ERR_UNSUPPORTED;
+    if (hq % hkv) return MV_ERR_UNSUPPORTED;
+    const int g = hq / hkv;
+    if (g != 1 && g != 2 && g != 4 && g != 8) return MV_ERR_UNSUPPORTED;
+    if ((page & (page - 1)) || page < 64) return MV_ERR_UNSUPPORTED;  // a 64-key tile sits in one page
+    if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out) ||
+        (q_stride % 8) != 0 || (out_stride % 4) != 0 || q_stride < (int64_t)hq * d ||
+        out_stride < (int64_t)hq * d)
+        return MV_ERR_INVALID_ARG;
+    PfArgs a;
+    a.q = (const uint16_t*)q;
+    a.q_stride = q_stride;
+    a.k_cache = (const uint16_t*)k_cache;
+    a.v_cache = (const uint16_t*)v_cache;
+    a.start = cache_seqlens;
+    a.block_table = block_table;
+    a.bt_stride = bt_stride;
+    a.out = (uint16_t*)out;
+    a.out_stride = out_stride;
+    a.B = bs;
+    a.S = seq;
+    a.hq = hq;
+    a.hkv = hkv;
+    a.g = g;
+    a.qt = 128 / g;
+    a.qt_shift = __builtin_ctz((unsigned)a.qt);
+    a.nqb = (seq + a.qt - 1) / a.qt;
+    a.page = page;
+    a.page_shift = __builtin_ctz((unsigned)page);
+    a.num_pages = num_pages;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    const int64_t grid = (int64_t)a.nqb * hkv * bs;
+    if (grid > 0x7fffffffLL) return MV_ERR_UNSUPPORTED;
+    if (d == 128)
+        hipLaunchKernelGGL(paged_attn_prefill_kernel<128>, dim3((unsigned)grid), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(paged_attn_prefill_kernel<64>, dim3((unsigned)grid), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -115,14 +115,17 @@ class RefRunner:
             trace.append(h)
         return self.head(h)
 
-    def prefill(self, input_ids, caches, block_table):
+    def prefill(self, input_ids, caches, block_table, trace=None):
         """model_prefill.py:23-62: fixed-length batch [B,S], RoPE outside the attention call with
-        positions 0..S-1, cache_seqlens zeroed, logits for every position."""
+        positions 0..S-1, cache_seqlens zeroed, logits for every position.  `trace` (a list)
+        receives the hidden state [B,S,hid] entering each layer and the final one."""
         tr = self.model.transformer
         B, S = input_ids.shape
         h = tr.wte.weight[input_ids]                                               # :29
         zeros = torch.zeros(B, dtype=torch.int32)                                  # :32
         for li, block in enumerate(tr.h):
+            if trace is not None:
+                trace.append(h)
             normed = rmsnorm_ref(h, block.ln_1.weight, block.ln_1.eps)             # :41
             parts = []
             for r, sh in enumerate(self.shards):
@@ -142,5 +145,7 @@ class RefRunner:
                 gu = linear_ref(normed, w["gu"])                                   # :58 (_mlp)
                 parts.append(linear_ref(swiglu_ref(gu), w["d"]))
             h = (self._allreduce(parts).float() + residual.float()).to(BF16)       # :59
+        if trace is not None:
+            trace.append(h)
         h = rmsnorm_ref(h, tr.ln_f.weight, tr.ln_f.eps)                            # :61
         return linear_ref(h, self.lm_head)                                         # :62
