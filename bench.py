@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--ctx", type=int, default=4096)
     ap.add_argument("--layers", type=int, default=0, help="build only this many layers (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prefill", action="store_true", help="skip the prefill leg of the report")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="per-projection GB/s table on stderr")
     return ap.parse_args()
@@ -79,6 +80,52 @@ def build(args, dev, world):
         ok, _ = mgr.alloc(sid, args.ctx)
         assert ok, "KV pool too small"
     return cfg, layers, runner, mgr
+
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X
+
+
+def prefill_leg(args, cfg, layers, runner, dev, reps=3):
+    """Second half of the metric: one fixed-length prefill of `ctx` tokens (bs 1) through
+    ModelPrefillRunner on the same weight image, KV pages written, last-token logits.  Timed with
+    HIP events on the current stream; flops = 2 * params * tokens + causal attention."""
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+    from micro_vllm_amd.core.layer.model_prefill import ModelPrefillRunner
+
+    S = args.ctx
+    blocks = (S + 255) // 256 + 1
+    pre = ModelPrefillRunner(runner.model, layers, runner.num_heads, runner.head_size, runner.kv_num_heads,
+                             runner.hidden_dim, runner.intermediate_size, dev, max_batch_size=1,
+                             max_blocks=max(32, blocks), release_source_weights=True)
+    mgr = KVCacheManager(blocks + 1, 256, layers, runner.kv_num_heads, runner.head_size,
+                         dtype=torch.bfloat16, device=dev, max_tokens=blocks * 256, max_batch_size=1)
+    order = list(mgr._free)
+    random.Random(2).shuffle(order)
+    mgr._free.clear()
+    mgr._free.extend(order)
+    assert mgr.alloc(0, S)[0]
+    mgr.cache_batch_data([0], [S])
+    ids = torch.randint(0, cfg.vocab_size, (1, S), generator=torch.Generator().manual_seed(0)).to(dev)
+    for _ in range(2):
+        logits = pre.forward(ids, mgr, 1, last_token_only=True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        logits = pre.forward(ids, mgr, 1, last_token_only=True)
+    e1.record()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(logits.float()).all()), "non-finite prefill logits"
+    t = e0.elapsed_time(e1) * 1e-3 / reps
+    hid, inter = cfg.hidden_size, cfg.intermediate_size // 2
+    qkv_dim = (cfg.num_attention_heads + 2 * cfg.num_key_value_heads) * cfg.head_dim
+    flops = 2.0 * S * layers * (hid * qkv_dim + hid * hid + 3 * hid * inter) + 2.0 * hid * cfg.vocab_size \
+        + 4.0 * layers * cfg.num_attention_heads * cfg.head_dim * S * S / 2
+    return {"metric": "prefill tokens/sec", "value": round(S / t, 1), "unit": "tokens/s",
+            "ms": round(t * 1e3, 3), "seq_len": S, "batch": 1, "bound": "mfma",
+            "achieved_TFLOPs": round(flops / t / 1e12, 1), "peak_TFLOPs": MFMA_PEAK_TFLOPS,
+            "frac": round(flops / t / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "logits": "last position only (what the engine samples from)"}
 
 
 def gemm_only_timing(runner, bs, layers, reps=20):
@@ -346,6 +393,12 @@ def main():
             out["roofline"] = None
         if args.shapes:
             shape_table(runner, bs, layers)
+        if world == 1 and not args.no_prefill:
+            try:
+                out["prefill"] = prefill_leg(args, cfg, layers, runner, dev)
+            except Exception as e:
+                log(f"[bench] prefill leg failed: {e!r}")
+                out["prefill"] = None
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, cfg, runner, dev)

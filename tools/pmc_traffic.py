@@ -1,0 +1,47 @@
+"""HBM traffic per launch of the dominant decode kernel from two rocprofv3 --pmc passes
+(FETCH_SIZE and WRITE_SIZE, each collected in a run of its own):
+
+  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> KEY
+
+FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts 64 bytes per
+128-byte request of a wide streaming read, so it is doubled.  Writes the per-launch average
+(bytes) under KEY into profiles/traffic.json, which bench.py reads for roofline.traffic.
+"""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def per_launch(path, counter, kernel_substr):
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter or kernel_substr not in r["Kernel_Name"]:
+            continue
+        tot += float(r["Counter_Value"])
+        n += 1
+    return tot, n
+
+
+def main():
+    fetch_csv, write_csv, key = sys.argv[1:4]
+    kernel = key.split(":")[0]
+    f, nf = per_launch(fetch_csv, "FETCH_SIZE", kernel)
+    w, nw = per_launch(write_csv, "WRITE_SIZE", kernel)
+    assert nf > 0 and nw > 0, "no dispatches of the kernel in the counter files"
+    fetch_b = f * 1024 * 2 / nf
+    write_b = w * 1024 / nw
+    out = os.path.join(ROOT, "profiles", "traffic.json")
+    d = json.load(open(out)) if os.path.exists(out) else {}
+    d[key] = int(fetch_b + write_b)
+    d[key + ":detail"] = {"launches": nf, "fetch_bytes_per_launch": int(fetch_b),
+                          "write_bytes_per_launch": int(write_b),
+                          "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE KiB x 1024"}
+    json.dump(d, open(out, "w"), indent=1, sort_keys=True)
+    print(json.dumps({key: d[key], "detail": d[key + ":detail"]}))
+
+
+if __name__ == "__main__":
+    main()
