@@ -123,7 +123,8 @@ int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_
 /* Launch-shape knobs for experiments (no counterpart in the reference):
  * key 0 = workgroups per CU the grid is sized for (1..8; 0 = planner, the default);
  * key 1 = forced number of k-slices per strip (0 = pick automatically);
- * key 2 = waves per workgroup of the M <= 4 kernel (8 or 16; 0 = planner). */
+ * key 2 = waves per workgroup of the M <= 4 kernel (8 or 16; 0 = planner);
+ * key 3 = strips a workgroup of the M > 4 kernel multiplies together (1, 2, 4; 0 = planner). */
 int mv_wgemm_tune(int key, int value);
 
 /* y[M,N] = x[M,K] . W^T for many rows (prefill) on the matrix cores, reading the same tile image

@@ -31,6 +31,7 @@ constexpr int kMaxKsplit = 8;
 
 static int g_tune_bpc = 0;      // workgroups per CU the grid is sized for (0 = planner)
 static int g_tune_waves = 0;    // waves per workgroup of the dot form: 8 or 16 (0 = planner)
+static int g_tune_sg = 0;       // strips per workgroup of the MFMA form: 1, 2 or 4 (0 = planner)
 static int g_tune_ksplit = 0;   // 0 = heuristic
 
 enum { kProNone = 0, kProNorm = 1, kProAddNorm = 2 };
@@ -378,11 +379,14 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------ M > 4: MFMA form
-// MB = number of 16-row blocks of x (M <= 16*MB).
-template <int MB>
+// MB = number of 16-row blocks of x (M <= 16*MB); SG = strips a workgroup multiplies together.
+// A wave loads the x fragments of a k-tile once and uses them against the SG weight tiles of
+// that k-tile: x comes out of L2 for every workgroup, so without the sharing the x requests
+// (MB per weight tile) outnumber the weight requests and the L2 path, not HBM, sets the pace.
+template <int MB, int SG>
 __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
-    constexpr int U = (MB <= 2) ? 4 : 2;  // tiles per stage (register budget)
-    __shared__ __attribute__((aligned(16))) float red[kGW * MB * 64 * 4];
+    constexpr int U = (SG + MB <= 6) ? 2 : 1;  // k-tiles per stage (register budget)
+    __shared__ __attribute__((aligned(16))) float red[kGW * SG * MB * 64 * 4];
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -394,37 +398,47 @@ __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
     for (int b = 0; b < MB; ++b) xrow[b] = a.x + (int64_t)min(b * 16 + r, a.m - 1) * a.ldx + q * 8;
 
     for (int u = blockIdx.x; u < a.nunits; u += gridDim.x) {
-        const int nt = u / a.ksplit, ks = u - nt * a.ksplit;
+        const int g = u / a.ksplit, ks = u - g * a.ksplit;
         const int kt0 = ks * a.ktps;
         const int kt1 = min(a.kt, kt0 + a.ktps);
         const int ntile = (kt1 - kt0 - wid + kGW - 1) / kGW;
-        const uint4* wbase = a.w + ((int64_t)nt * a.kt + kt0 + wid) * 64 + lane;
         const int last = max(ntile - 1, 0);
-
-        f32x4_t acc[MB];
+        const int ktw = kt0 + (ntile > 0 ? wid : 0);  // a wave without tiles still loads (clamped)
+        const uint4* wbase[SG];
 #pragma unroll
-        for (int b = 0; b < MB; ++b) acc[b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int sI = 0; sI < SG; ++sI)
+            wbase[sI] = a.w + ((int64_t)min(g * SG + sI, a.nt - 1) * a.kt + ktw) * 64 + lane;
 
-        uint4 wA[U], wB[U], xA[U][MB], xB[U][MB];
-        auto load = [&](uint4(&wb)[U], uint4(&xb)[U][MB], int c) {
+        f32x4_t acc[SG][MB];
+#pragma unroll
+        for (int sI = 0; sI < SG; ++sI)
+#pragma unroll
+            for (int b = 0; b < MB; ++b) acc[sI][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        uint4 wA[U][SG], wB[U][SG], xA[U][MB], xB[U][MB];
+        auto load = [&](uint4(&wb)[U][SG], uint4(&xb)[U][MB], int c) {
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 const int t = min(c * U + i, last);
-                wb[i] = ld16_nt(wbase + (int64_t)t * (kGW * 64));
-                const int kcol = (kt0 + wid + t * kGW) * 32;
+#pragma unroll
+                for (int sI = 0; sI < SG; ++sI) wb[i][sI] = ld16_nt(wbase[sI] + (int64_t)t * (kGW * 64));
+                const int kcol = (ktw + t * kGW) * 32;
 #pragma unroll
                 for (int b = 0; b < MB; ++b) xb[i][b] = ld16(xrow[b] + kcol);
             }
         };
-        auto compute = [&](const uint4(&wb)[U], const uint4(&xb)[U][MB], int c) {
+        auto compute = [&](const uint4(&wb)[U][SG], const uint4(&xb)[U][MB], int c) {
 #pragma unroll
             for (int i = 0; i < U; ++i) {
                 if (c * U + i < ntile) {  // wave-uniform
-                    const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wb[i]);
 #pragma unroll
-                    for (int b = 0; b < MB; ++b)
-                        acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            wf, __builtin_bit_cast(bf16x8_t, xb[i][b]), acc[b], 0, 0, 0);
+                    for (int sI = 0; sI < SG; ++sI) {
+                        const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wb[i][sI]);
+#pragma unroll
+                        for (int b = 0; b < MB; ++b)
+                            acc[sI][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                wf, __builtin_bit_cast(bf16x8_t, xb[i][b]), acc[sI][b], 0, 0, 0);
+                    }
                 }
             }
         };
@@ -438,23 +452,27 @@ __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
             if (c + 1 < nchunk) compute(wB, xB, c + 1);
         }
 
-        // acc[b][j] = C[n = 4q + j][m = 16b + r]
+        // acc[s][b][j] = C[n = 16 (g SG + s) + 4q + j][m = 16b + r]
 #pragma unroll
-        for (int b = 0; b < MB; ++b)
-            *reinterpret_cast<f32x4_t*>(&red[((wid * MB + b) * 64 + lane) * 4]) = acc[b];
+        for (int sI = 0; sI < SG; ++sI)
+#pragma unroll
+            for (int b = 0; b < MB; ++b)
+                *reinterpret_cast<f32x4_t*>(&red[(((wid * SG + sI) * MB + b) * 64 + lane) * 4]) = acc[sI][b];
         __syncthreads();
-        if (threadIdx.x < 64 * MB) {
-            const int b = threadIdx.x >> 6, l = threadIdx.x & 63;
+        if (threadIdx.x < 64 * MB * SG) {
+            const int sb = threadIdx.x >> 6, l = threadIdx.x & 63;
+            const int sI = sb / MB, b = sb - sI * MB;
             const int rr = l & 15, qq = l >> 4;
             const int m = b * 16 + rr;
+            const int nt = g * SG + sI;
             auto sum_at = [&](int ll) {
                 f32x4_t s = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int w8 = 0; w8 < kGW; ++w8)
-                    s += *reinterpret_cast<const f32x4_t*>(&red[((w8 * MB + b) * 64 + ll) * 4]);
+                    s += *reinterpret_cast<const f32x4_t*>(&red[(((w8 * SG + sI) * MB + b) * 64 + ll) * 4]);
                 return s;
             };
-            if (m < a.m) {
+            if (m < a.m && nt < a.nt) {
                 const f32x4_t s = sum_at(l);
                 const int n0 = nt * 16 + qq * 4;
                 if (a.ksplit > 1) {
@@ -464,10 +482,10 @@ __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
                         &reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n0]) = s;
                 } else if (a.flags & MV_GEMM_SWIGLU) {
                     if (qq < 2) {  // rows 0..7 = up; their gates sit 8 rows (32 lanes) further
-                        const f32x4_t g = sum_at(l + 32);
+                        const f32x4_t gt = sum_at(l + 32);
                         uint2 o;
-                        o.x = pack_bf16x2(silu_mul_rounded(g[0], s[0]), silu_mul_rounded(g[1], s[1]));
-                        o.y = pack_bf16x2(silu_mul_rounded(g[2], s[2]), silu_mul_rounded(g[3], s[3]));
+                        o.x = pack_bf16x2(silu_mul_rounded(gt[0], s[0]), silu_mul_rounded(gt[1], s[1]));
+                        o.y = pack_bf16x2(silu_mul_rounded(gt[2], s[2]), silu_mul_rounded(gt[3], s[3]));
                         *reinterpret_cast<uint2*>(&reinterpret_cast<uint16_t*>(
                             a.y)[(int64_t)m * a.ldy + nt * 8 + qq * 4]) = o;
                     }
@@ -515,7 +533,14 @@ __global__ __launch_bounds__(256) void wgemm_finalize_kernel(GemmArgs a) {
 // ------------------------------------------------------------ host planning
 // k-slices per strip: balance whole units over the CUs.  Cost in tiles per CU,
 // with a split paying roughly one extra kernel boundary.
-static int pick_ksplit(int nt, int kt) {
+static int mfma_strip_group(int mb);
+
+// `nt` = work items along N: strips for the dot form, strip groups for the MFMA form.
+static int pick_ksplit(int m, int nt, int kt) {
+    if (m > 4) {
+        const int sg = mfma_strip_group((m + 15) / 16);
+        nt = (nt + sg - 1) / sg;
+    }
     if (g_tune_ksplit > 0) {
         int ks = g_tune_ksplit;
         while (ks > 1 && (kt % ks) != 0) --ks;
@@ -569,10 +594,16 @@ static int launch_dot_waves(const GemmArgs& a, int waves, int grid, hipStream_t 
     return waves == 16 ? launch_dot_pro<M, 16>(a, grid, s) : launch_dot_pro<M, 8>(a, grid, s);
 }
 
-template <int MB>
+template <int MB, int SG>
 static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL(wgemm_mfma_kernel<MB>, dim3(grid), dim3(kGT), 0, s, a);
+    hipLaunchKernelGGL((wgemm_mfma_kernel<MB, SG>), dim3(grid), dim3(kGT), 0, s, a);
     return check_launch();
+}
+
+// strips per workgroup of the MFMA form: SG * MB <= 8 keeps the cross-wave reduction in 64 KiB
+static int mfma_strip_group(int mb) {
+    if (g_tune_sg == 1 || g_tune_sg == 2 || (g_tune_sg == 4 && mb <= 2)) return g_tune_sg;
+    return mb <= 2 ? 4 : 2;
 }
 
 static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_r,
@@ -623,7 +654,7 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     a.eps = eps;
     a.sum_out = (uint16_t*)sum_out;
     a.ld_sum_out = ld_sum_out;
-    a.ksplit = pick_ksplit(a.nt, a.kt);
+    a.ksplit = pick_ksplit(m, a.nt, a.kt);
     a.partial = nullptr;
     if (a.ksplit > 1) {
         const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
@@ -634,7 +665,8 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
         }
     }
     a.ktps = a.kt / a.ksplit;
-    a.nunits = a.nt * a.ksplit;
+    const int sg = m > 4 ? mfma_strip_group((m + 15) / 16) : 1;
+    a.nunits = ((a.nt + sg - 1) / sg) * a.ksplit;
     a.flags = flags;
 
     const int cus = num_cus();
@@ -663,10 +695,10 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
         case 4: rc = launch_dot_waves<4>(a, waves, grid, s); break;
         default: {
             const int mb = (m + 15) / 16;
-            if (mb == 1) rc = launch_mfma<1>(a, grid, s);
-            else if (mb == 2) rc = launch_mfma<2>(a, grid, s);
-            else if (mb == 3) rc = launch_mfma<3>(a, grid, s);
-            else rc = launch_mfma<4>(a, grid, s);
+            if (mb == 1) rc = sg == 4 ? launch_mfma<1, 4>(a, grid, s) : sg == 2 ? launch_mfma<1, 2>(a, grid, s) : launch_mfma<1, 1>(a, grid, s);
+            else if (mb == 2) rc = sg == 4 ? launch_mfma<2, 4>(a, grid, s) : sg == 2 ? launch_mfma<2, 2>(a, grid, s) : launch_mfma<2, 1>(a, grid, s);
+            else if (mb == 3) rc = sg == 2 ? launch_mfma<3, 2>(a, grid, s) : launch_mfma<3, 1>(a, grid, s);
+            else rc = sg == 2 ? launch_mfma<4, 2>(a, grid, s) : launch_mfma<4, 1>(a, grid, s);
         }
     }
     if (rc != MV_OK) return rc;
@@ -685,10 +717,15 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
 extern "C" {
 
 // Tuning hook for experiments: key 0 = workgroups per CU, key 1 = forced ksplit,
-// key 2 = waves per workgroup of the dot form (8 or 16); 0 = let the planner choose.
+// key 2 = waves per workgroup of the dot form (8 or 16), key 3 = strips per workgroup of the
+// MFMA form (1, 2, 4); 0 = let the planner choose.
 int mv_wgemm_tune(int key, int value) {
     if (key == 2 && (value == 0 || value == 8 || value == 16)) {
         mv::g_tune_waves = value;
+        return MV_OK;
+    }
+    if (key == 3 && (value == 0 || value == 1 || value == 2 || value == 4)) {
+        mv::g_tune_sg = value;
         return MV_OK;
     }
     if (key == 0 && value >= 0 && value <= 8) {
@@ -706,7 +743,7 @@ size_t mv_wgemm_workspace_bytes(int m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
     // slabs for the split the planner picks now; a call that later finds the
     // workspace too small (tuning changed) runs unsplit instead of failing
-    const int ks = mv::pick_ksplit(n / 16, k / 32);
+    const int ks = mv::pick_ksplit(m, n / 16, k / 32);
     return ks > 1 ? (size_t)ks * (size_t)m * (size_t)n * sizeof(float) : 0;
 }
 
