@@ -1,0 +1,220 @@
+"""Engine glue around the two runners: request intake, one scheduler decision per step, prefill /
+decode drivers, token bookkeeping.  Mirrors the reference's InferenceEngine
+(core/engine.py:35-309) method for method; the model and tokenizer are handed in as objects
+(checkpoint loading is a separate concern), and the KV pool geometry is a constructor argument
+instead of the reference's fixed 81 blocks / 4-column block table.
+"""
+import logging
+import time
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .cache_manager import KVCacheManager
+from .inference_context import BatchInferenceContext
+from .layer.model_graph import ModelGraphRunner
+from .layer.model_prefill import ModelPrefillRunner
+from .layer.sampler import Sampler, greedy
+from .parallel_config import get_rank, get_world_size, rank0, setup
+from .scheduler import Scheduler
+from .sequence import Sequence
+
+logger = logging.getLogger("InferenceEngine")
+
+
+@dataclass
+class InferenceStats:
+    prep_time: float = 0.0
+    gpu_time: float = 0.0
+    sample_time: float = 0.0
+    total_time: float = 0.0
+
+
+class InferenceEngine:
+    DEFAULT_BLOCK_SIZE = 256
+    DEFAULT_MAX_BLOCKS = 81
+
+    def __init__(self, model_path: Optional[str] = None, max_batch_size: int = 40,
+                 max_prefill_tokens: int = 2048, *, model=None, tokenizer=None,
+                 n_blocks: Optional[int] = None, max_tokens: int = 1024,
+                 graph_batch_sizes: Optional[List[int]] = None, prefill_timeout: float = 0.02):
+        """`max_tokens` is the longest sequence a block-table row can describe (the reference's
+        KVCacheManager default, 1024, gives four columns - pass more for long contexts)."""
+        setup()
+        self.rank = get_rank()
+        if model is None:
+            raise NotImplementedError(
+                "checkpoint loading is not part of this path: pass model= and tokenizer= "
+                f"(got model_path={model_path!r})")
+        assert torch.cuda.is_available(), "the HIP library is the only compute path"
+        torch.cuda.set_device(self.rank % max(1, torch.cuda.device_count()))
+        self.device, self.dtype = "cuda", torch.bfloat16
+        self.model, self.tokenizer = model, tokenizer
+        self.config = model.config
+
+        # per-rank geometry (core/engine.py:101-114)
+        cfg = self.config
+        world = get_world_size()
+        self.num_layers = cfg.num_hidden_layers
+        heads = cfg.num_attention_heads
+        kv_heads = getattr(cfg, "num_key_value_heads", heads)
+        self.head_size = getattr(cfg, "head_dim", cfg.hidden_size // heads)
+        assert heads % world == 0 and kv_heads % world == 0
+        self.num_heads, self.kv_num_heads = heads // world, kv_heads // world
+        self.intermediate_size = cfg.intermediate_size // world
+
+        blocks = n_blocks if n_blocks is not None else self.DEFAULT_MAX_BLOCKS
+        self.cache_manager = KVCacheManager(
+            n_blocks=blocks, block_size=self.DEFAULT_BLOCK_SIZE, n_layers=self.num_layers,
+            n_heads=self.kv_num_heads, head_size=self.head_size, dtype=self.dtype, device=self.device,
+            max_tokens=max_tokens, max_batch_size=max_batch_size)
+        max_blocks = max(32, (max_tokens + 255) // 256)
+        runner_args = dict(model=model, num_layers=self.num_layers, num_heads=self.num_heads,
+                           head_size=self.head_size, kv_num_heads=self.kv_num_heads,
+                           hidden_dim=cfg.hidden_size, intermediate_size=self.intermediate_size,
+                           device=self.device, max_batch_size=max_batch_size, dtype=self.dtype,
+                           max_blocks=max_blocks)
+        self.graph_runner = ModelGraphRunner(**runner_args)
+        self.prefill_runner = ModelPrefillRunner(**runner_args)
+        self.scheduler = Scheduler(max_batch_size, max_prefill_tokens, tokenizer, prefill_timeout)
+        self.sampler = Sampler()
+
+        self.eos_token_id = getattr(tokenizer, "eos_token_id", None)
+        self.stream_callbacks = {}
+        self.max_position = getattr(cfg, "max_position_embeddings", 4096)
+        sizes = graph_batch_sizes or [b for b in (1, 2, 4, 8, 16, 32, 40) if b <= max_batch_size]
+        self.scheduler.batch_sizes = [b for b in sizes if b <= max_batch_size] or [max_batch_size]
+        self.graph_runner.capture(self.cache_manager, batch_sizes=self.scheduler.batch_sizes)
+
+    def shutdown(self):
+        try:
+            if torch.distributed.is_initialized():
+                torch.distributed.destroy_process_group()
+        except Exception as e:  # best effort at exit
+            logger.warning("error during shutdown: %s", e)
+
+    # ------------------------------------------------------------------ public API
+    def add_request(self, prompt: str, max_tokens: int = 128, temperature: float = 0.7,
+                    top_p: float = 0.9) -> int:
+        seq_id = hash(prompt + str(time.time())) % (2 ** 32)
+        seq = Sequence(seq_id, prompt, self.tokenizer, max_tokens)
+        seq.temperature, seq.top_p = temperature, top_p
+        self.scheduler.add_request(seq)
+        return seq_id
+
+    def register_stream_callback(self, seq_id: int, callback):
+        self.stream_callbacks[seq_id] = callback
+
+    def unregister_stream_callback(self, seq_id: int):
+        self.stream_callbacks.pop(seq_id, None)
+
+    def get_next_batch(self) -> Tuple[List[Sequence], str]:
+        return self.scheduler.get_next_batch()
+
+    @torch.inference_mode()
+    def step(self, ctx: BatchInferenceContext) -> bool:
+        if not ctx.sequences:
+            return False
+        if ctx.batch_type == "prefill":
+            self._prefill(ctx.sequences)
+        else:
+            self._decode(ctx.sequences)
+        return True
+
+    def generate(self, prompts: List[str], max_tokens: int = 100, temperature: float = 0.7,
+                 top_p: float = 0.9) -> Dict[str, str]:
+        """Run the prompts to completion on this process (single-rank event loop).  Unlike the
+        reference's `generate` (core/engine.py:178-199), which never applies the sampled tokens
+        and so returns nothing, this loop calls `update_sequences` after every step the way the
+        server loop does (api_server.py:64-76)."""
+        seq_ids = [self.add_request(p, max_tokens, temperature, top_p) for p in prompts]
+        by_id = dict(zip(seq_ids, prompts))
+        results = {}
+        budget = (max_tokens + 2) * max(1, len(prompts)) + 16
+        for _ in range(budget * 50):
+            batch, kind = self.get_next_batch()
+            if kind == "waiting":
+                time.sleep(self.scheduler.prefill_timeout / 4)
+                continue
+            if not batch:
+                break
+            ctx = BatchInferenceContext(len(batch), kind, batch)
+            self.step(ctx)
+            self.update_sequences(ctx.sequences)
+        for seq, ids in self.scheduler.get_finished_results():
+            try:
+                results[by_id[seq.seq_id]] = self.tokenizer.decode(ids, skip_special_tokens=True)
+            except Exception:
+                results[by_id.get(seq.seq_id, str(seq.seq_id))] = "[Error]"
+        self.scheduler.running_sequences.clear()
+        return results
+
+    # ------------------------------------------------------------------ step drivers
+    def _sample(self, logits, temps, topp, top_k):
+        if bool((temps <= 0).all()):
+            return greedy(logits.contiguous()).tolist()          # deterministic limit, on device
+        temps = temps.clamp_min(1e-5)
+        return self.sampler(logits, temps, topp, min(top_k, logits.shape[-1])).tolist()
+
+    def _prefill(self, batch: List[Sequence]):
+        """core/engine.py:205-239: the batch arrives right-padded to one length; pages for that
+        length are allocated for every sequence; the token is sampled from the LAST position."""
+        device = self.device
+        input_ids = torch.tensor([seq.get_next_input_ids() for seq in batch], dtype=torch.long, device=device)
+        temps = torch.tensor([seq.temperature for seq in batch], device=device)
+        topp = torch.tensor([seq.top_p for seq in batch], device=device)
+        seq_lens = [input_ids.shape[1]] * len(batch)
+        for seq in batch:
+            ok, _ = self.cache_manager.alloc(seq.seq_id, seq_lens[0])
+            if not ok:
+                raise RuntimeError("OOM")
+        self.cache_manager.cache_batch_data([s.seq_id for s in batch], seq_lens)
+        logits = self.prefill_runner.forward(input_ids, self.cache_manager, len(batch), last_token_only=True)
+        if rank0():
+            next_tokens = self._sample(logits[:, -1, :], temps, topp, 1000)
+            for i, seq in enumerate(batch):
+                seq._next_token = next_tokens[i]
+
+    def _decode(self, batch: List[Sequence]):
+        """core/engine.py:241-285: padded batches repeat sequences, so appends are de-duplicated;
+        cache_seqlens = current_position (already advanced past the prompt)."""
+        device = self.device
+        batch_size = len(batch)
+        seen, first = set(), []
+        for seq in batch:
+            first.append(seq.seq_id not in seen)
+            seen.add(seq.seq_id)
+        input_ids = torch.tensor([seq.get_next_input_ids() for seq in batch], device=device).squeeze(1)
+        temps = torch.tensor([seq.temperature for seq in batch], device=device)
+        topp = torch.tensor([seq.top_p for seq in batch], device=device)
+        for i, seq in enumerate(batch):
+            if first[i] and self.cache_manager.append(seq.seq_id) == -1:
+                raise RuntimeError("OOM")
+        self.cache_manager.cache_batch_data([s.seq_id for s in batch], [s.current_position for s in batch])
+        logits = self.graph_runner.forward(input_ids, self.cache_manager, batch_size)
+        if rank0():
+            next_tokens = self._sample(logits, temps, topp, 50)
+            for i, seq in enumerate(batch):
+                seq._next_token = next_tokens[i]
+
+    def update_sequences(self, sequences: List[Sequence]):
+        """core/engine.py:287-309: apply each sequence's sampled token once, stream it, retire
+        finished sequences and return their pages."""
+        done = set()
+        for seq in sequences:
+            if seq._next_token is None or seq.seq_id in done:
+                continue
+            done.add(seq.seq_id)
+            seq.update_state(seq._next_token, None)
+            if rank0():
+                cb = self.stream_callbacks.get(seq.seq_id)
+                if cb is not None:
+                    try:
+                        cb(seq._next_token, self.tokenizer.decode([seq._next_token], skip_special_tokens=True))
+                    except Exception:
+                        pass
+            if seq.is_finished():
+                self.cache_manager.free(seq.seq_id)
+                if rank0():
+                    self.scheduler.mark_finished(seq)

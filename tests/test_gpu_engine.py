@@ -1,0 +1,135 @@
+"""InferenceEngine end to end on the GPU (stub tokenizer, tiny random-weight model, greedy):
+scheduler -> prefill -> decode with the reference's position numbering, against a loop that drives
+the CPU oracle (RefRunner + RefKVCache) with the same scheduler decisions."""
+import pytest
+import torch
+
+from oracle.ref_cache import RefKVCache
+from oracle.ref_model import RefRunner
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+class Tok:
+    eos_token_id = 2
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def encode(self, prompt, add_special_tokens=True):
+        return [5 + (ord(c) * 7) % (self.vocab - 5) for c in prompt]
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(i) for i in ids)
+
+
+def _oracle_generate(cfg, cpu_model, tok, prompts, max_new, n_blocks, max_tokens, max_bs):
+    """The same policy by hand: one prefill batch per scheduler decision, then decode groups."""
+    from micro_vllm_amd.core.scheduler import Scheduler
+    from micro_vllm_amd.core.sequence import Sequence
+
+    ref = RefRunner(cpu_model, cfg.head_dim, world=1, max_blocks=max(32, (max_tokens + 255) // 256))
+    cache = RefKVCache(n_blocks, 256, cfg.num_hidden_layers, cfg.num_key_value_heads, cfg.head_dim,
+                       max_tokens=max_tokens, max_batch_size=max_bs, strict_reference=False)
+    sch = Scheduler(max_bs, 2048, tok, prefill_timeout=0.0)
+    sch.batch_sizes = [b for b in (1, 2, 4, 8) if b <= max_bs]
+    seqs = [Sequence(i, p, tok, max_new) for i, p in enumerate(prompts)]
+    for s in seqs:
+        sch.add_request(s)
+    caches = [(cache.k_caches, cache.v_caches)]
+    for _ in range(10000):
+        batch, kind = sch.get_next_batch()
+        if not batch:
+            break
+        ids_list = [s.get_next_input_ids() for s in batch]
+        if kind == "prefill":
+            S = len(ids_list[0])
+            for s in batch:
+                assert cache.alloc(s.seq_id, S)[0]
+            bt, _ = cache.cache_batch_data([s.seq_id for s in batch], [S] * len(batch))
+            logits = ref.prefill(torch.tensor(ids_list), caches, bt)[:, -1]
+        else:
+            seen = set()
+            for s in batch:
+                if s.seq_id not in seen:
+                    cache.append(s.seq_id)
+                    seen.add(s.seq_id)
+            bt, sl = cache.cache_batch_data([s.seq_id for s in batch], [s.current_position for s in batch])
+            logits = ref.decode(torch.tensor(ids_list).squeeze(1), caches, sl, bt)
+        nxt = logits.float().argmax(-1).tolist()
+        done = set()
+        for s, t in zip(batch, nxt):
+            if s.seq_id in done:
+                continue
+            done.add(s.seq_id)
+            s.update_state(t, None)
+            if s.is_finished():
+                cache.free(s.seq_id)
+                sch.mark_finished(s)
+    return {s.prompt: s.output_ids for s in seqs}, logits
+
+
+def test_engine_generate_matches_the_oracle_loop(mv):
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES["tiny-gqa"]
+    tok = Tok(cfg.vocab_size)
+    cpu_model = build_synthetic_model(cfg, "cpu", seed=1234, norm_jitter=0.1)
+    gpu_model = build_synthetic_model(cfg, "cpu", seed=1234, norm_jitter=0.1).to(DEV)
+    prompts = ["a" * 12, "bc" * 9, "hello world, this is a longer prompt " * 2, "zz"]
+    max_new = 6
+    eng = InferenceEngine(model=gpu_model, tokenizer=tok, max_batch_size=4, n_blocks=24, max_tokens=1024,
+                          graph_batch_sizes=[1, 2, 4], prefill_timeout=0.0)
+    collected = {}
+    for p in prompts:
+        sid = eng.add_request(p, max_tokens=max_new, temperature=0.0)
+        collected[sid] = []
+        eng.register_stream_callback(sid, lambda t, txt, sid=sid: collected[sid].append(t))
+    by_id = {s.seq_id: s for s in eng.scheduler.waiting_queue}
+    from micro_vllm_amd.core.inference_context import BatchInferenceContext
+    kinds = []
+    for _ in range(1000):
+        batch, kind = eng.get_next_batch()
+        if not batch:
+            break
+        kinds.append((kind, len(batch)))
+        ctx = BatchInferenceContext(len(batch), kind, batch)
+        assert eng.step(ctx)
+        eng.update_sequences(ctx.sequences)
+    got = {s.prompt: s.output_ids for s in by_id.values()}
+    want, _ = _oracle_generate(cfg, cpu_model, tok, prompts, max_new, 24, 1024, 4)
+    assert kinds[0][0] == "prefill" and any(k == "decode" for k, _ in kinds)
+    # Greedy decoding is discontinuous in the logits: a near-tie between the top two can flip
+    # and the continuations then differ legitimately.  Require identical first tokens for every
+    # prompt (prefill parity) and full agreement for at least three of the four continuations.
+    agree = 0
+    for p in prompts:
+        assert len(got[p]) >= 1 and len(got[p]) <= max_new
+        assert got[p][0] == want[p][0], f"first token differs for {p!r}: {got[p]} vs {want[p]}"
+        agree += int(got[p] == want[p])
+    assert agree >= 3, (got, want)
+    for sid, toks in collected.items():
+        assert toks == by_id[sid].output_ids          # every token streamed exactly once
+    assert eng.cache_manager.stats["free"] == 24      # every page returned
+    assert not eng.scheduler.running_sequences or all(s.is_finished() for s in eng.scheduler.running_sequences)
+
+
+def test_engine_generate_api_and_sampling_path(mv):
+    """`generate` drains its prompts; with temperature > 0 the stochastic sampler runs on the device
+    and returns valid ids."""
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES["tiny-mha"]
+    tok = Tok(cfg.vocab_size)
+    gpu_model = build_synthetic_model(cfg, "cpu", seed=7, qkv_bias=True).to(DEV)
+    eng = InferenceEngine(model=gpu_model, tokenizer=tok, max_batch_size=2, n_blocks=12, max_tokens=512,
+                          graph_batch_sizes=[1, 2], prefill_timeout=0.0)
+    torch.manual_seed(0)
+    out = eng.generate(["first prompt", "second"], max_tokens=5, temperature=0.8, top_p=0.9)
+    assert set(out) == {"first prompt", "second"}
+    for text in out.values():
+        ids = [int(t) for t in text.split()]
+        assert all(0 <= t < cfg.vocab_size for t in ids)
