@@ -107,3 +107,72 @@ def test_two_ranks_on_one_gpu_match_the_oracle(fused, bs):
     assert bool((err <= tol).all()), f"max err {err.max().item()}"
     assert err.mean().item() <= 2e-3
     assert bool((got[0][0].argmax(-1) == want.argmax(-1)).all())
+
+
+def _prefill_worker(rank, world, port, S, out_q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVLLM_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import micro_vllm_amd  # noqa: F401
+    from micro_vllm_amd.core import parallel_config as pc
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+    from micro_vllm_amd.core.layer.model_prefill import ModelPrefillRunner
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    torch.cuda.set_device(0)
+    pc.setup()
+    dev = "cuda"
+    cfg = SHAPES["tiny-gqa"]
+    model = build_synthetic_model(cfg, "cpu", seed=1234, qkv_bias=True).to(dev)
+    hkv = cfg.num_key_value_heads // world
+    runner = ModelPrefillRunner(model, cfg.num_hidden_layers, cfg.num_attention_heads // world,
+                                cfg.head_dim, hkv, cfg.hidden_size, cfg.intermediate_size // world, dev,
+                                max_batch_size=2)
+    mgr = KVCacheManager(8, 256, cfg.num_hidden_layers, hkv, cfg.head_dim, dtype=torch.bfloat16,
+                         device=dev, max_tokens=1024, max_batch_size=2)
+    for sid in range(2):
+        assert mgr.alloc(sid, S)[0]
+    mgr.cache_batch_data([0, 1], [S, S])
+    ids = torch.randint(0, cfg.vocab_size, (2, S), generator=torch.Generator().manual_seed(11))
+    logits = runner.forward(ids.to(dev), mgr, 2).float().cpu()
+    bt = mgr._block_table_buffer[:2].cpu()
+    pc.barrier()
+    out_q.put((rank, logits.numpy(), bt.numpy()))
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+def test_two_rank_prefill_matches_the_oracle():
+    """ModelPrefillRunner under TP=2: column/row-parallel matrix-core GEMMs, per-rank kv heads and
+    pages, all-reduce of [B*S, hid] after O and after down."""
+    sys.path.insert(0, ROOT)
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+    from oracle.ref_model import RefRunner
+
+    S = 70
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prefill_worker, args=(r, 2, port, S, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, lg, bt = q.get(timeout=300)
+        got[r] = (torch.from_numpy(lg), torch.from_numpy(bt))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(got[0][0], got[1][0]), "ranks disagree"
+
+    cfg = SHAPES["tiny-gqa"]
+    model = build_synthetic_model(cfg, "cpu", seed=1234, qkv_bias=True)
+    hkv = cfg.num_key_value_heads // 2
+    caches = [([torch.zeros(8, 256, hkv, cfg.head_dim, dtype=torch.bfloat16) for _ in range(cfg.num_hidden_layers)],
+               [torch.zeros(8, 256, hkv, cfg.head_dim, dtype=torch.bfloat16) for _ in range(cfg.num_hidden_layers)])
+              for _ in range(2)]
+    ids = torch.randint(0, cfg.vocab_size, (2, S), generator=torch.Generator().manual_seed(11))
+    want = RefRunner(model, cfg.head_dim, world=2, p_bf16=True).prefill(ids, caches, got[0][1]).float()
+    err = (got[0][0] - want).abs()
+    assert err.mean().item() <= 4e-3
+    assert err.max().item() <= 4 * 2.0 ** -7 * float(want.abs().max())
