@@ -216,6 +216,18 @@ int mv_store_kv(const void* key, const void* value, int64_t kv_stride_t, void* k
  * done on the device so the step needs no [bs,V] sort and no host round trip. */
 int mv_argmax(const void* logits, int64_t ld, int rows, int n, int64_t* ids, mv_stream_t stream);
 
+/* Stochastic pick, one launch per batch: for each row, scale by 1/temperature[r], keep the
+ * min(top_k, n, 1024) largest logits, softmax over them, keep the sorted prefix whose inclusive
+ * cumulative probability is < top_p[r] (always at least the first), renormalise, and return the
+ * entry at which the cumulative probability first exceeds uniforms[r] (a number in [0,1) the caller
+ * draws).  Equal logits are ordered by ascending index, so the result is a deterministic function of
+ * its inputs; temperature <= 0 returns the argmax.  n must be a multiple of 8.
+ * The recipe of core/layer/sampler.py:21-43 (_sample_impl: topk, softmax, sort, cumsum < top_p,
+ * multinomial), with the draw expressed through an explicit uniform number. */
+int mv_sample_topk_topp(const void* logits, int64_t ld, int rows, int n, const float* temperatures,
+                        const float* top_ps, int top_k, const float* uniforms, int64_t* ids,
+                        mv_stream_t stream);
+
 /* ------------------------------------------------------------ hipGraph */
 
 /* Capture everything launched on `stream` between begin and end into an

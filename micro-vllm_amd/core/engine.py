@@ -154,7 +154,8 @@ class InferenceEngine:
     def _sample(self, logits, temps, topp, top_k):
         if bool((temps <= 0).all()):
             return greedy(logits.contiguous()).tolist()          # deterministic limit, on device
-        temps = temps.clamp_min(1e-5)
+        # one launch: temperature, top-k, softmax, top-p and the draw (rows with temperature 0 are
+        # resolved greedily inside the kernel)
         return self.sampler(logits, temps, topp, min(top_k, logits.shape[-1])).tolist()
 
     def _prefill(self, batch: List[Sequence]):

@@ -1,7 +1,11 @@
-"""Token selection.  `greedy` is the device-side argmax (mv_argmax, csrc/sampler.hip): the
-temperature -> 0 limit of the reference's Sampler (core/layer/sampler.py:4-43), which is the
-deterministic - hence parity-checkable - case.  `Sampler` keeps the reference's call signature;
-its stochastic branch follows the same top-k / top-p / multinomial recipe with torch ops."""
+"""Token selection on the device (csrc/sampler.hip).
+
+`greedy` = mv_argmax, the temperature -> 0 limit of the reference's Sampler
+(core/layer/sampler.py:4-43).  `sample` = mv_sample_topk_topp: the reference's whole recipe
+(temperature, top-k, softmax, top-p, draw) in one launch, the draw being the inverse CDF of a
+uniform number per row.  `Sampler` keeps the reference's call signature and uses `sample` for
+bf16 logits on the GPU; `_sample_impl` is the reference's recipe in torch ops, kept as the
+statistical comparison point."""
 import torch
 
 from ... import _native as nv
@@ -21,8 +25,36 @@ def greedy(logits: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
     return out[:bs]
 
 
+def sample(logits: torch.Tensor, temperatures: torch.Tensor, top_ps: torch.Tensor, top_k: int,
+           uniforms: torch.Tensor = None, out: torch.Tensor = None, generator=None) -> torch.Tensor:
+    """logits [bs,V] bf16 -> int64 [bs]; `uniforms` [bs] in [0,1) (drawn here when not given).
+    No host synchronisation."""
+    assert logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2
+    assert logits.stride(1) == 1
+    bs, v = logits.shape
+    dev = logits.device
+    temperatures = temperatures.to(device=dev, dtype=torch.float32).contiguous()
+    top_ps = top_ps.to(device=dev, dtype=torch.float32).contiguous()
+    if uniforms is None:
+        uniforms = torch.rand(bs, device=dev, dtype=torch.float32, generator=generator)
+    uniforms = uniforms.to(device=dev, dtype=torch.float32).contiguous()
+    assert temperatures.numel() == bs and top_ps.numel() == bs and uniforms.numel() == bs
+    if out is None:
+        out = torch.empty(bs, dtype=torch.long, device=dev)
+    assert out.dtype == torch.long and out.is_contiguous() and out.numel() >= bs
+    ld = logits.stride(0) if bs > 1 else max(v, logits.stride(0))
+    nv.check("mv_sample_topk_topp", nv.lib().mv_sample_topk_topp(
+        logits.data_ptr(), ld, bs, v, temperatures.data_ptr(), top_ps.data_ptr(), int(top_k),
+        uniforms.data_ptr(), out.data_ptr(), nv.stream_ptr()))
+    return out[:bs]
+
+
 class Sampler:
     def __call__(self, logits, temperatures, top_ps, top_k):
+        if logits.is_cuda and logits.dtype == torch.bfloat16 and logits.shape[-1] % 8 == 0:
+            if logits.stride(-1) != 1 or (logits.dim() == 2 and logits.stride(0) % 8):
+                logits = logits.contiguous()
+            return sample(logits, temperatures, top_ps, top_k)
         return self._sample_impl(logits, temperatures, top_ps, top_k)
 
     @staticmethod

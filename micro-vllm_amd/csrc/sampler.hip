@@ -1,5 +1,12 @@
-// Greedy token pick: ids[r] = argmax_c logits[r, c] (lowest index on ties), one workgroup per row.
-// Reads the bf16 logits row once with 16-byte loads.
+// Token selection on the device, one workgroup per row of bf16 logits.
+//   argmax_kernel : greedy pick (lowest index on ties); reads the row once with 16-byte loads.
+//   sample_kernel : temperature -> top-k -> softmax -> top-p -> draw, the recipe of the reference's
+//                   Sampler._sample_impl (core/layer/sampler.py:21-43), as one launch instead of
+//                   topk + softmax + sort + cumsum + multinomial + two gathers.  The k largest
+//                   logits are found by a two-pass radix select on the 16 bf16 bits (division by a
+//                   positive temperature does not change the order), gathered into LDS (ties at
+//                   the threshold by ascending index, so the result is deterministic), sorted there
+//                   (bitonic), and the draw is the inverse CDF of the caller's uniform number.
 #include "common.h"
 
 namespace mv {
@@ -48,7 +55,222 @@ __global__ __launch_bounds__(kAmThreads) void argmax_kernel(const uint16_t* __re
     }
 }
 
+// ---------------------------------------------------------------- top-k / top-p sampling
+constexpr int kSmThreads = 1024;
+constexpr int kSmMaxK = 1024;
+
+// order-preserving 16-bit key of a bf16 value (larger key = larger value); NaN sorts lowest
+__device__ __forceinline__ unsigned bf16_key(unsigned bits) {
+    if ((bits & 0x7f80u) == 0x7f80u && (bits & 0x7fu)) return 0u;
+    return (bits & 0x8000u) ? (~bits & 0xffffu) : (bits | 0x8000u);
+}
+
+// inclusive scan over the workgroup (one value per thread); `ws` holds one slot per wave
+template <typename T>
+__device__ __forceinline__ T block_scan_incl(T v, T* ws, T& total) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T u = __shfl_up(v, o, 64);
+        if (lane >= o) v += u;
+    }
+    __syncthreads();  // ws may still be read from a previous scan
+    if (lane == 63) ws[wid] = v;
+    __syncthreads();
+    T base = 0, tot = 0;
+    for (int w = 0; w < kSmThreads / 64; ++w) {
+        const T x = ws[w];
+        if (w < wid) base += x;
+        tot += x;
+    }
+    total = tot;
+    return v + base;
+}
+
+__global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __restrict__ logits,
+                                                          int64_t ld, int n,
+                                                          const float* __restrict__ temps,
+                                                          const float* __restrict__ top_ps, int top_k,
+                                                          const float* __restrict__ uniforms,
+                                                          int64_t* __restrict__ ids) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_u[8];
+    __shared__ float c_val[kSmMaxK];
+    __shared__ int c_idx[kSmMaxK];
+    __shared__ float ws_f[kSmThreads / 64];
+    __shared__ unsigned ws_u[kSmThreads / 64];
+
+    const int tid = threadIdx.x;
+    const uint16_t* row = logits + (int64_t)blockIdx.x * ld;
+    const int nvec = n >> 3;
+    const int k = min(min(top_k, n), kSmMaxK);
+
+    auto for_each = [&](auto&& fn) {  // fn(key, index) over the row, 16-byte loads
+        for (int c = tid; c < nvec; c += kSmThreads) {
+            const uint4 v = ld16(row + c * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                fn(bf16_key(w[j] & 0xffffu), c * 8 + 2 * j);
+                fn(bf16_key(w[j] >> 16), c * 8 + 2 * j + 1);
+            }
+        }
+    };
+    // the bin (scanning from the top) in which the running count reaches `want`
+    auto pick_bin = [&](unsigned want, unsigned& bin, unsigned& above) {
+        __syncthreads();
+        if (tid == 0) {
+            unsigned acc = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (acc + hist[b] >= want) break;
+                acc += hist[b];
+            }
+            sh_u[0] = (unsigned)b;
+            sh_u[1] = acc;
+        }
+        __syncthreads();
+        bin = sh_u[0];
+        above = sh_u[1];
+        __syncthreads();
+    };
+
+    // ---- radix select of the k-th largest key: high byte, then low byte
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for_each([&](unsigned key, int) { atomicAdd(&hist[key >> 8], 1u); });
+    unsigned b1, above1;
+    pick_bin((unsigned)k, b1, above1);
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for_each([&](unsigned key, int) {
+        if ((key >> 8) == b1) atomicAdd(&hist[key & 255u], 1u);
+    });
+    unsigned b2, above2;
+    pick_bin((unsigned)k - above1, b2, above2);
+    const unsigned thr = (b1 << 8) | b2;
+    const unsigned n_gt = above1 + above2;           // keys strictly above the threshold (< k)
+    const unsigned need_eq = (unsigned)k - n_gt;     // threshold-valued entries to take, lowest indices first
+
+    // ---- gather: keys above the threshold in any order, threshold ties in index order
+    if (tid == 0) sh_u[2] = 0;
+    __syncthreads();
+    unsigned eq_base = 0;
+    const int nchunk = (nvec + kSmThreads - 1) / kSmThreads;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int c = ch * kSmThreads + tid;
+        unsigned keys[8];
+        unsigned my_eq = 0;
+        if (c < nvec) {
+            const uint4 v = ld16(row + c * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                keys[2 * j] = bf16_key(w[j] & 0xffffu);
+                keys[2 * j + 1] = bf16_key(w[j] >> 16);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (keys[j] > thr) {
+                    const unsigned slot = atomicAdd(&sh_u[2], 1u);
+                    const uint32_t wj = w[j >> 1];
+                    c_val[slot] = (j & 1) ? bf16_hi(wj) : bf16_lo(wj);
+                    c_idx[slot] = c * 8 + j;
+                }
+                my_eq += (keys[j] == thr);
+            }
+        }
+        if (eq_base < need_eq) {  // uniform: eq_base is the same in every thread
+            unsigned total;
+            const unsigned incl = block_scan_incl(my_eq, ws_u, total);
+            unsigned rank = eq_base + incl - my_eq;
+            if (c < nvec && my_eq) {
+                const uint4 v = ld16(row + c * 8);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (keys[j] == thr) {
+                        if (rank < need_eq) {
+                            const uint32_t wj = w[j >> 1];
+                            c_val[n_gt + rank] = (j & 1) ? bf16_hi(wj) : bf16_lo(wj);
+                            c_idx[n_gt + rank] = c * 8 + j;
+                        }
+                        ++rank;
+                    }
+                }
+            }
+            eq_base += total;
+        }
+    }
+    // pad to a power of two for the sort
+    int p2 = 1;
+    while (p2 < k) p2 <<= 1;
+    __syncthreads();
+    if (tid >= k && tid < p2) {
+        c_val[tid] = -INFINITY;
+        c_idx[tid] = 0x7fffffff;
+    }
+    // ---- bitonic sort, descending by value, ascending index among equals
+    for (int size = 2; size <= p2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            const int i = tid, j = tid ^ stride;
+            if (i < p2 && j > i) {
+                const float vi = c_val[i], vj = c_val[j];
+                const int ii = c_idx[i], ij = c_idx[j];
+                const bool i_first = (vi > vj) || (vi == vj && ii < ij);  // i belongs before j
+                const bool want_first = (i & size) == 0;
+                if (i_first != want_first) {
+                    c_val[i] = vj;
+                    c_val[j] = vi;
+                    c_idx[i] = ij;
+                    c_idx[j] = ii;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- softmax over the k candidates, top-p prefix, inverse-CDF draw
+    const float temp = temps[blockIdx.x];
+    if (!(temp > 0.f)) {  // uniform: greedy limit
+        if (tid == 0) ids[blockIdx.x] = c_idx[0];
+        return;
+    }
+    const float smax = c_val[0] / temp;
+    const float e = tid < k ? expf(c_val[tid] / temp - smax) : 0.f;
+    float total;
+    const float cum = block_scan_incl(e, ws_f, total);
+    const float cump = cum / total;
+    const float top_p = top_ps[blockIdx.x];
+    const unsigned valid = (tid < k) && (cump < top_p || tid == 0);
+    unsigned m;
+    block_scan_incl(valid, ws_u, m);               // the valid set is a prefix: m = its length
+    if (tid == (int)m - 1) ws_f[0] = cump;           // mass kept
+    __syncthreads();
+    const float target = uniforms[blockIdx.x] * ws_f[0];
+    __syncthreads();
+    const unsigned below = (tid < (int)m) && (cump <= target);
+    unsigned nb;
+    block_scan_incl(below, ws_u, nb);
+    if (tid == 0) ids[blockIdx.x] = c_idx[min(nb, m - 1)];
+}
+
 }  // namespace mv
+
+extern "C" int mv_sample_topk_topp(const void* logits, int64_t ld, int rows, int n,
+                                   const float* temperatures, const float* top_ps, int top_k,
+                                   const float* uniforms, int64_t* ids, mv_stream_t stream) {
+    if (rows == 0 && n > 0) return MV_OK;
+    if (!logits || !ids || !temperatures || !top_ps || !uniforms || rows < 0 || n <= 0 || ld < n ||
+        top_k <= 0)
+        return MV_ERR_INVALID_ARG;
+    if (!mv::aligned16(logits) || (ld % 8) != 0) return MV_ERR_INVALID_ARG;
+    if ((n % 8) != 0) return MV_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(mv::sample_kernel, dim3(rows), dim3(mv::kSmThreads), 0, (hipStream_t)stream,
+                       (const uint16_t*)logits, ld, n, temperatures, top_ps, top_k, uniforms, ids);
+    return mv::check_launch();
+}
 
 extern "C" int mv_argmax(const void* logits, int64_t ld, int rows, int n, int64_t* ids,
                          mv_stream_t stream) {
