@@ -271,6 +271,7 @@ def main():
     if world == 1 and args.gpus > 1:
         log(f"--gpus {args.gpus} needs the torch.distributed.run launcher; running 1 GPU")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    local %= torch.cuda.device_count()  # rehearsals put several ranks on one GPU (gloo backend)
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
 
@@ -359,7 +360,7 @@ def main():
             "seq_len": args.ctx,
             "layers": layers,
             "parallelism": f"tp{world}",
-            "graph": not args.no_graph,
+            "graph": bs in runner._graphs,   # False when capture was skipped or fell back to eager
             "sampling": "greedy argmax on device",
         },
         "step_algorithmic_GB": round(step_bytes / 1e9, 3),

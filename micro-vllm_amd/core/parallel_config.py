@@ -21,7 +21,7 @@ def setup():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world > 1 and not dist.is_initialized():
         if torch.cuda.is_available() and os.environ.get("MVLLM_DIST_BACKEND", "nccl") != "gloo":
-            local = int(os.environ.get("LOCAL_RANK", rank))
+            local = int(os.environ.get("LOCAL_RANK", rank)) % torch.cuda.device_count()
             torch.cuda.set_device(local)
             dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local))
