@@ -533,12 +533,12 @@ __global__ __launch_bounds__(256) void wgemm_finalize_kernel(GemmArgs a) {
 // ------------------------------------------------------------ host planning
 // k-slices per strip: balance whole units over the CUs.  Cost in tiles per CU,
 // with a split paying roughly one extra kernel boundary.
-static int mfma_strip_group(int mb);
+static int mfma_strip_group(int mb, int nt);
 
 // `nt` = work items along N: strips for the dot form, strip groups for the MFMA form.
 static int pick_ksplit(int m, int nt, int kt) {
     if (m > 4) {
-        const int sg = mfma_strip_group((m + 15) / 16);
+        const int sg = mfma_strip_group((m + 15) / 16, nt);
         nt = (nt + sg - 1) / sg;
     }
     if (g_tune_ksplit > 0) {
@@ -601,9 +601,18 @@ static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
 }
 
 // strips per workgroup of the MFMA form: SG * MB <= 8 keeps the cross-wave reduction in 64 KiB
-static int mfma_strip_group(int mb) {
-    if (g_tune_sg == 1 || g_tune_sg == 2 || (g_tune_sg == 4 && mb <= 2)) return g_tune_sg;
-    return mb <= 2 ? 4 : 2;
+static int mfma_strip_group(int mb, int nt) {
+    const int most = mb <= 2 ? 4 : 2;
+    if (g_tune_sg == 1 || g_tune_sg == 2 || (g_tune_sg == 4 && most == 4)) return g_tune_sg;
+    // From sweeps (tools/sweep_mfma_gemv.py).  Two or more row blocks of x: always the widest
+    // group - the x traffic out of L2 dominates otherwise (M=32, down projection: 41.7 us with
+    // single strips against 25.9 us with groups of four).  One row block: the largest group that
+    // still leaves about one workgroup per CU, because sharing only pays once every CU has work.
+    if (mb >= 2) return most;
+    const int want = num_cus() * 3 / 4;
+    for (int sg = most; sg > 1; sg >>= 1)
+        if ((nt + sg - 1) / sg >= want) return sg;
+    return 1;
 }
 
 static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_r,
@@ -665,7 +674,7 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
         }
     }
     a.ktps = a.kt / a.ksplit;
-    const int sg = m > 4 ? mfma_strip_group((m + 15) / 16) : 1;
+    const int sg = m > 4 ? mfma_strip_group((m + 15) / 16, a.nt) : 1;
     a.nunits = ((a.nt + sg - 1) / sg) * a.ksplit;
     a.flags = flags;
 

@@ -55,6 +55,10 @@ SHAPES = {
     "llama3-8b": SyntheticConfig("llama3-8b", 128256, 4096, 32, 32, 8, 128, 14336, 1e-5),
     # Llama-3-70B
     "llama3-70b": SyntheticConfig("llama3-70b", 128256, 8192, 80, 64, 8, 128, 28672, 1e-5),
+    # one rank's slice of Llama-3-70B under 8-way tensor parallelism (heads, kv heads and FFN columns
+    # divided by 8; hidden size, vocabulary and layer count unchanged): per-GPU kernel work of that
+    # configuration without the all-reduces
+    "llama3-70b-tp8shard": SyntheticConfig("llama3-70b-tp8shard", 128256, 8192, 80, 8, 1, 128, 3584, 1e-5),
     # small shapes for tests (all kernel paths, seconds on a CPU)
     "tiny-gqa": SyntheticConfig("tiny-gqa", 512, 256, 2, 8, 2, 64, 512, 1e-6, 2048),
     "tiny-mha": SyntheticConfig("tiny-mha", 512, 256, 2, 4, 4, 64, 384, 1e-6, 2048),
