@@ -5,9 +5,10 @@
 // one fully coalesced 1 KiB request per tile, and only x passes through LDS.
 //
 // Workgroup = 4 waves = 256 (n) x 128 (m) outputs; wave w owns n-tiles 4w..4w+3 against all
-// eight m-tiles (128 fp32 accumulators per lane).  x tiles of 128 rows x 64 k are staged in
-// LDS twice buffered (row stride 144 B: conflict-free 16-byte fragment reads); the weight
-// fragments of the next k-tile are requested while the current one is multiplied.
+// eight m-tiles (128 fp32 accumulators per lane).  x tiles of 128 rows x 64 k go global -> LDS
+// directly, three stages deep, in fragment order; half of a k-tile's x fragments are read while
+// the previous k-tile is still being multiplied; weight fragments are requested two k-tiles
+// before they are multiplied.
 //
 // Workgroups are numbered so that the ones resident together on an XCD (blockIdx mod 8) share
 // few n-blocks and many m-blocks: each weight fragment is then fetched into that XCD's L2 once
@@ -23,11 +24,18 @@ namespace mv {
 constexpr int kPM = 128;            // rows of x per workgroup
 constexpr int kPN = 256;            // output columns per workgroup
 constexpr int kPK = 64;             // k per LDS stage
-constexpr int kPRow = kPK * 2 + 16; // LDS row stride in bytes
+constexpr int kPStage = kPM * kPK * 2; // bytes of one x stage in LDS
 constexpr int kPMT = kPM / 16;      // m-tiles per wave
 constexpr int kPNT = 4;             // n-tiles per wave
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt in bits 3:0 and 15:14, the other counters at
+// their maxima)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | (7 << 4) | (15 << 8));
+}
 
 struct PGemmArgs {
     const uint16_t* x;
@@ -44,8 +52,25 @@ struct PGemmArgs {
     int flags;
 };
 
+#ifdef MV_GEMM_STAMP
+// Phase stamps of one wave (build variant for tools/stamp_gemm_prefill.py): s_memtime ticks at four
+// points of every k stage, for the workgroup selected by kStampBlock.  MV_EXP_NO_WLOAD /
+// MV_EXP_NO_XREAD additionally remove one operand path (wrong results, timing only).
+constexpr int kStampBlock = 777;
+static __device__ unsigned long long g_stamp[4 * 512];
+#define MV_STAMP(slot)                                                            \
+    do {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        if (blockIdx.x == kStampBlock && threadIdx.x == 0 && s < 512)             \
+            g_stamp[4 * s + (slot)] = __builtin_readcyclecounter();               \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    } while (0)
+#else
+#define MV_STAMP(slot) do {} while (0)
+#endif
+
 __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char xs[2][kPM * kPRow];
+    __shared__ __attribute__((aligned(16))) unsigned char xs[3][kPStage];
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -66,19 +91,38 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     for (int i = 0; i < kPNT; ++i)
         wp[i] = a.w + (int64_t)min(nt0 + i, a.nt - 1) * a.kt * 64 + lane;
 
-    // x staging: thread t moves vectors t + 256 j (j < 4) of the 128 x 8 vector tile
+    // ---- x: global -> LDS directly, three stages deep, in fragment order ---------------------
+    // The LDS image of a stage is 16 fragment tiles (8 m-tiles x 2 k-tiles) of 1 KiB in MFMA
+    // operand order: lane l of the tile (mt, kk) holds x[16 mt + (l & 15)][32 kk + 8 (l >> 4) ..+7],
+    // so a fragment read is linear in the lane (no bank conflicts).  Wave w fills tiles 4w..4w+3
+    // with global_load_lds (no staging registers, no LDS store instructions).  These loads are
+    // issued through inline assembly: when the compiler sees them it stops trusting request
+    // order and waits for ALL outstanding loads before every weight use and every LDS read;
+    // hidden from it they only make its counted waits wait for more (requests complete in
+    // order), never for less.  The wait that makes the data usable is placed by hand.
+    const int nstage = a.kt >> 1;  // K is a multiple of 64 (checked on the host)
     const uint16_t* xg[4];
-    int xl[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int v = threadIdx.x + 256 * j, row = v >> 3, k8 = v & 7;
-        xg[j] = a.x + (int64_t)min(m0 + row, a.m - 1) * a.ldx + k8 * 8;
-        xl[j] = row * kPRow + k8 * 16;
+        const int tile = wid * 4 + j;
+        xg[j] = a.x + (int64_t)min(m0 + (tile >> 1) * 16 + r, a.m - 1) * a.ldx + ((tile & 1) * 4 + q) * 8;
     }
-    const int nstage = a.kt >> 1;  // K is a multiple of 64 (checked on the host)
-    auto x_load = [&](uint4(&xr)[4], int s) {
+    const unsigned xs_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&xs[0][0];
+    auto x_fetch = [&](int s, int buf) {
+        const int sc = min(s, nstage - 1);  // past the end: a harmless re-fetch keeps the counts fixed
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xr[j] = ld16(xg[j] + s * kPK);
+        for (int j = 0; j < 4; ++j) {
+            const uint16_t* src = xg[j] + sc * kPK;
+            const unsigned dst = xs_base + buf * kPStage + (wid * 4 + j) * 1024;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+        }
+    };
+    auto x_frag = [&](int buf, int t, int kk) {
+#ifdef MV_EXP_NO_XREAD
+        return __builtin_bit_cast(bf16x8_t, make_uint4(lane, t, kk, buf));  // timing experiment only
+#endif
+        return __builtin_bit_cast(
+            bf16x8_t, *reinterpret_cast<const uint4*>(&xs[buf][(t * 2 + kk) * 1024 + lane * 16]));
     };
 
     f32x4_t acc[kPNT][kPMT];
@@ -87,47 +131,74 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
 #pragma unroll
         for (int t = 0; t < kPMT; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    uint4 xr[4], wc[kPNT], wn[kPNT];
-    x_load(xr, 0);
+    // weight fragments: a ring of three k-tiles, each refilled right after its MFMAs are issued
+    uint4 wA[kPNT], wB[kPNT], wC[kPNT];
+    auto w_load = [&](uint4(&w)[kPNT], int kt) {
+        const int ktc = min(kt, a.kt - 1);
 #pragma unroll
-    for (int i = 0; i < kPNT; ++i) wc[i] = ld16(wp[i]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(&xs[0][xl[j]]) = xr[j];
+        for (int i = 0; i < kPNT; ++i) {
+#ifdef MV_EXP_NO_WLOAD
+            if (kt > 2) continue;  // timing experiment only: weights never refreshed
+#endif
+            w[i] = ld16(wp[i] + (int64_t)ktc * 64);
+        }
+    };
+    x_fetch(0, 0);
+    x_fetch(1, 1);
+    w_load(wA, 0);
+    w_load(wB, 1);
+    w_load(wC, 2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    const int frag_off = r * kPRow + q * 16;
-    for (int s = 0; s < nstage; ++s) {
-        const unsigned char* xb = xs[s & 1];
-        const bool more = s + 1 < nstage;
-        if (more) x_load(xr, s + 1);
+    // x fragments of two k-tiles alternate between X0 and X1; the first half of a k-tile's
+    // fragments is read while the previous k-tile is still being multiplied
+    bf16x8_t X0[kPMT], X1[kPMT];
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            const int kt = 2 * s + kk;
-            {
-                const int ktn = min(kt + 1, a.kt - 1);
+    for (int t = 0; t < kPMT / 2; ++t) X0[t] = x_frag(0, t, 0);
+
+    // one k-tile: (buf, kk) = where it lives; (nbuf, nkk) = the k-tile after it
+    auto ktile = [&](uint4(&w)[kPNT], bf16x8_t(&xc)[kPMT], bf16x8_t(&xn)[kPMT], int buf, int kk, int nbuf,
+                     int nkk, int kt_refill) {
+        bf16x8_t wf[kPNT];
 #pragma unroll
-                for (int i = 0; i < kPNT; ++i) wn[i] = ld16(wp[i] + (int64_t)ktn * 64);
-                bf16x8_t xf[kPMT];
+        for (int i = 0; i < kPNT; ++i) wf[i] = __builtin_bit_cast(bf16x8_t, w[i]);
+        // (pinning this order with scheduling fences measured 3 % slower than letting the
+        // scheduler interleave reads and MFMAs itself)
 #pragma unroll
-                for (int t = 0; t < kPMT; ++t)
-                    xf[t] = __builtin_bit_cast(
-                        bf16x8_t, *reinterpret_cast<const uint4*>(xb + t * 16 * kPRow + kk * 64 + frag_off));
+        for (int t = kPMT / 2; t < kPMT; ++t) xc[t] = x_frag(buf, t, kk);
 #pragma unroll
-                for (int i = 0; i < kPNT; ++i) {
-                    const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wc[i]);
+        for (int t = 0; t < kPMT / 2; ++t)
 #pragma unroll
-                    for (int t = 0; t < kPMT; ++t)
-                        acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[t], acc[i][t], 0, 0, 0);
-                }
+            for (int i = 0; i < kPNT; ++i)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xc[t], acc[i][t], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < kPNT; ++i) wc[i] = wn[i];
-            }
-        }
-        if (more) {
+        for (int t = 0; t < kPMT / 2; ++t) xn[t] = x_frag(nbuf, t, nkk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(&xs[(s + 1) & 1][xl[j]]) = xr[j];
-        }
+        for (int t = kPMT / 2; t < kPMT; ++t)
+#pragma unroll
+            for (int i = 0; i < kPNT; ++i)
+                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xc[t], acc[i][t], 0, 0, 0);
+        w_load(w, kt_refill);
+    };
+    // One stage: request stage s+2 of x (its buffer was last read in stage s-1), two k-tiles, wait
+    // for this wave's part of stage s+2 (two weight refills were requested after it), barrier: the
+    // next stage's later reads and the stage after's early reads both see complete data.
+    auto stage = [&](uint4(&w0)[kPNT], uint4(&w1)[kPNT], int s, int b0, int b1, int b2) {
+        MV_STAMP(0);
+        x_fetch(s + 2, b2);
+        ktile(w0, X0, X1, b0, 0, b0, 1, 2 * s + 3);
+        ktile(w1, X1, X0, b0, 1, b1, 0, 2 * s + 4);
+        MV_STAMP(1);
+        wait_vmcnt<2 * kPNT>();
+        MV_STAMP(2);
         __syncthreads();
+        MV_STAMP(3);
+    };
+    for (int s = 0; s < nstage; s += 3) {
+        stage(wA, wB, s, 0, 1, 2);
+        if (s + 1 < nstage) stage(wC, wA, s + 1, 1, 2, 0);
+        if (s + 2 < nstage) stage(wB, wC, s + 2, 2, 0, 1);
     }
 
     // acc[i][t][j] = C[n = 16 (nt0+i) + 4q + j][m = m0 + 16 t + r]
@@ -177,6 +248,12 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
 }
 
 }  // namespace mv
+
+#ifdef MV_GEMM_STAMP
+extern "C" int mv_debug_read_stamps(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_stamp), bytes) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
                                const void* residual, int64_t ld_res, void* y, int64_t ldy, int m,
