@@ -186,9 +186,13 @@ class ModelGraphRunner:
             ctx = cache_manager._block_table_buffer.shape[1] * cache_manager.block_size
             ns = nv.lib().mv_paged_attn_decode_pick_splits(bs, self.kv_num_heads, ctx)
             self._num_splits[bs] = ns
-            need = nv.lib().mv_paged_attn_decode_workspace_bytes(self.max_bs, self.num_heads,
-                                                                 self.head_size, max(ns, 2))
-            if self._attn_ws is None or self._attn_ws.numel() * 4 < need:
+            if self._attn_ws is None:
+                # sized once for every batch size: captured graphs keep this pointer
+                L = nv.lib()
+                need = max(L.mv_paged_attn_decode_workspace_bytes(
+                    b, self.num_heads, self.head_size,
+                    max(L.mv_paged_attn_decode_pick_splits(b, self.kv_num_heads, ctx), 2))
+                    for b in range(1, self.max_bs + 1))
                 self._attn_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
         return ns
 

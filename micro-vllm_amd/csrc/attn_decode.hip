@@ -6,8 +6,10 @@
 // All G = Hq/Hkv query heads that share the kv head are scored against the row
 // while it is in registers (GQA reuse: KV bytes are read once per kv head).
 //
-// Work split: workgroup = (sequence b, kv head, kv split); its 4 waves interleave
-// over the split's rows.  Every 16-lane (D=128) / 8-lane (D=64) row group keeps
+// Work split: workgroup = (sequence b, kv head, kv split); its W waves interleave
+// over the split's rows (W = 4 when the launch has more workgroups than CUs; 16, or 8 for
+// G = 8, when it has fewer: with one workgroup per CU the rows of a split are then all
+// requested at once and the score arithmetic is spread over four times the waves).  Every 16-lane (D=128) / 8-lane (D=64) row group keeps
 // its own online-softmax state (m, l, acc[G][8]); states meet once in LDS at the
 // end.  Splits write normalised fp32 partials + log2-sum-exp with write-through stores
 // and take a ticket on a per-(b, kv head) arrival counter; the workgroup that draws the
@@ -22,10 +24,10 @@
 
 namespace mv {
 
-constexpr int kAW = 4;           // waves per workgroup
-constexpr int kAT = kAW * 64;    // 256 threads
-constexpr int kAC = 4;           // row loads per wave per pipeline stage
 constexpr float kNegBig = -1.0e30f;
+// Arrival counters sit 256 bytes apart: tickets of different (sequence, kv head) pairs are then
+// served by different L2 channels instead of queueing on one cache line.
+constexpr int kArriveStride = 64;
 
 struct AttnArgs {
     const uint16_t* q;
@@ -83,8 +85,27 @@ __device__ __forceinline__ void rope8(const uint4& x, const uint4& partner, cons
     }
 }
 
-template <int D, int G>
-__global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
+#ifdef MV_ATTN_STAMP
+// Phase stamps (build variant for tools/stamp_attn_decode.py): the constant 100 MHz counter at
+// up to sixteen points of every workgroup, written by its first thread.
+static __device__ unsigned long long g_astamp[16 * 4096];
+#define MV_ASTAMP(slot)                                                             \
+    do {                                                                            \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+        if (threadIdx.x == 0 && blockIdx.x < 4096)                                  \
+            g_astamp[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+        __builtin_amdgcn_sched_barrier(0);                                          \
+    } while (0)
+#else
+#define MV_ASTAMP(slot) do {} while (0)
+#endif
+
+template <int D, int G, int W>
+__global__ __launch_bounds__(W * 64) void paged_attn_decode_kernel(AttnArgs a) {
+    constexpr int kAW = W;          // waves per workgroup
+    constexpr int kAT = W * 64;     // threads per workgroup
+    constexpr bool WIDE = W > 4;    // 128 registers per lane: shorter stages, both requested up front
+    constexpr int kAC = WIDE ? 2 : 4;  // row loads per wave per pipeline stage
     constexpr int LPR = D / 8;      // lanes per row
     constexpr int RPI = 64 / LPR;   // rows per wave instruction
     constexpr int NS = kAW * RPI;   // softmax states per workgroup
@@ -97,6 +118,7 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lr = lane % LPR, tg = lane / LPR;
     const int d0 = lr * 8;
+    MV_ASTAMP(0);
 
     const int split = blockIdx.x % a.nsplit;
     const int bh = blockIdx.x / a.nsplit;
@@ -106,6 +128,9 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
     const int pos = a.seqlens[b];  // keys 0..pos-1 are cached, the new key lands at pos
     const int32_t* bt = a.block_table + (int64_t)b * a.bt_stride;
 
+#ifdef MV_ATTN_STAMP
+    if (pos >= 0) MV_ASTAMP(11);
+#endif
     // rows of this split: [t0, t1) of the cached keys
     int tps = (pos + a.nsplit - 1) / a.nsplit;
     tps = (tps + NS - 1) / NS * NS;
@@ -147,7 +172,11 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
     if (nchunk > 0) {
         load_pages(pgA, 0);
         if (nchunk > 1) load_pages(pgB, 1);
+#ifdef MV_ATTN_STAMP
+        if (pgA[0] >= -1) MV_ASTAMP(12);
+#endif
         load_rows(kA, vA, okA, pgA, 0);
+        if (WIDE && nchunk > 1) load_rows(kB, vB, okB, pgB, 1);
     }
 
     // ---- q (G heads) and the new k/v: load, rotate, round ----------------------
@@ -252,10 +281,14 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
         }
     };
 
+    MV_ASTAMP(1);
     for (int c = 0; c < nchunk; c += 2) {  // chunk 0 rows and chunk 1 page ids are already in flight
         if (c + 2 < nchunk) load_pages(pgA, c + 2);
-        if (c + 1 < nchunk) load_rows(kB, vB, okB, pgB, c + 1);
+        if (!(WIDE && c == 0) && c + 1 < nchunk) load_rows(kB, vB, okB, pgB, c + 1);
         absorb(kA, vA, okA);
+#ifdef MV_ATTN_STAMP
+        if (c == 0) MV_ASTAMP(8);
+#endif
         if (c + 3 < nchunk) load_pages(pgB, c + 3);
         if (c + 2 < nchunk) load_rows(kA, vA, okA, pgA, c + 2);
         if (c + 1 < nchunk) absorb(kB, vB, okB);
@@ -289,6 +322,7 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
     }
 
     // ---- merge the NS states ----------------------------------------------------
+    MV_ASTAMP(2);
     const int sidx = wid * RPI + tg;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -301,21 +335,24 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
         *reinterpret_cast<f32x4_t*>(dst + 4) = (f32x4_t){acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
     }
     __syncthreads();
-    // weights 2^(m_s - max) once per (state, head), written over st_m; st_l gets l_s * w_s
-    if (threadIdx.x < G) {
-        const int g = threadIdx.x;
+    // weights 2^(m_s - max) once per (state, head), written over st_m; one wave per head, one
+    // state per lane.  Head g's totals land in st_l[g] and st_l[G + g], both entries of its own
+    // states 0 and 1, which only this wave reads.
+    for (int g = wid; g < G; g += kAW) {
         float mx = kNegBig;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) mx = fmaxf(mx, st_m[s * G + g]);
+        for (int s = lane; s < NS; s += 64) mx = fmaxf(mx, st_m[s * G + g]);
+        mx = wave_max(mx);
         float lt = 0.f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
+        for (int s = lane; s < NS; s += 64) {
             const float w = __builtin_amdgcn_exp2f(st_m[s * G + g] - mx);
             lt = __builtin_fmaf(st_l[s * G + g], w, lt);
             st_m[s * G + g] = w;
         }
-        st_l[g] = lt;            // total normaliser of head g
-        st_l[G + g] = mx;        // its reference maximum
+        lt = wave_sum(lt);
+        if (lane == 0) {
+            st_l[g] = lt;            // total normaliser of head g
+            st_l[G + g] = mx;        // its reference maximum
+        }
     }
     __syncthreads();
     for (int o = threadIdx.x; o < G * D; o += kAT) {
@@ -340,18 +377,21 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    MV_ASTAMP(3);
     if (a.nsplit == 1 || a.arrive == nullptr) return;
 
     // ---- last-arriving split of this (b, kv head) merges all splits ---------------------
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
     __syncthreads();
+    MV_ASTAMP(4);
     int* flag = reinterpret_cast<int*>(lds);          // the state arrays are dead past the barrier
     if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.arrive + bh, 1u, __ATOMIC_RELAXED,
+        const unsigned old = __hip_atomic_fetch_add(a.arrive + (int64_t)bh * kArriveStride, 1u, __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT);
         *flag = (old == (unsigned)a.nsplit - 1u);
     }
     __syncthreads();
+    MV_ASTAMP(5);
     if (!*flag) return;
     __syncthreads();  // everyone has read the flag before LDS is reused
     // Every load of handed-off data below is an sc1 (L1-bypassing) load.  Each thread owns one
@@ -361,7 +401,7 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
     constexpr int ITEMS = G * D / 4;
     constexpr int PARTS = kAT / ITEMS;
     static_assert(ITEMS * PARTS == kAT, "one (item, part) per thread");
-    constexpr int kMU = 16;  // loads in flight per thread
+    constexpr int kMU = PARTS >= 8 ? 4 : 16;  // loads in flight per thread
     const int ns = a.nsplit;
     float* wts = lds;                 // [G][nsplit] weights 2^(lse - max) / sum
     float* psum = lds + G * 128;      // [PARTS][ITEMS][4] (nsplit <= 128)
@@ -376,28 +416,44 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
             v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((mg * ns + sp) * D + md4) * 4, 0, 16 /*sc1*/);
         }
     };
+    // One wave per head turns its log-sum-exps into normalised weights, one split per lane (two
+    // when there are more than 64 splits); the partial loads are in flight meanwhile.
+    float lse0 = kNegBig, lse1 = kNegBig;
+    const int wg0 = wid;  // first head of this wave
+    if (wg0 < G) {
+        const int64_t pi = ((int64_t)b * a.hq + kvh * G + wg0) * ns;
+        if (lane < ns)
+            lse0 = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(a.part_lse + pi + lane),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (lane + 64 < ns)
+            lse1 = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(a.part_lse + pi + lane + 64),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
     u32x4_t v0[kMU];
     load_batch(v0, part);
-    for (int i = threadIdx.x; i < G * ns; i += kAT) {
-        const int g = i / ns, sp = i - g * ns;
-        const int64_t pi = ((int64_t)b * a.hq + kvh * G + g) * ns + sp;
-        wts[i] = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(a.part_lse + pi),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-    __syncthreads();
-    if (threadIdx.x < G) {
-        float* w = wts + threadIdx.x * ns;
-        float mx = kNegBig;
-        for (int sp = 0; sp < ns; ++sp) mx = fmaxf(mx, w[sp]);
-        float sum = 0.f;
-        for (int sp = 0; sp < ns; ++sp) {
-            w[sp] = __builtin_amdgcn_exp2f(w[sp] - mx);
-            sum += w[sp];
+    for (int g = wg0; g < G; g += kAW) {
+        if (g != wg0) {  // only when there are more heads than waves
+            const int64_t pi = ((int64_t)b * a.hq + kvh * G + g) * ns;
+            lse0 = lane < ns ? __uint_as_float(__hip_atomic_load(
+                                   reinterpret_cast<unsigned int*>(a.part_lse + pi + lane), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT))
+                             : kNegBig;
+            lse1 = lane + 64 < ns ? __uint_as_float(__hip_atomic_load(
+                                        reinterpret_cast<unsigned int*>(a.part_lse + pi + lane + 64),
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                  : kNegBig;
         }
+        const float mx = wave_max(fmaxf(lse0, lse1));
+        const float w0 = lane < ns ? __builtin_amdgcn_exp2f(lse0 - mx) : 0.f;
+        const float w1 = lane + 64 < ns ? __builtin_amdgcn_exp2f(lse1 - mx) : 0.f;
+        const float sum = wave_sum(w0 + w1);
         const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-        for (int sp = 0; sp < ns; ++sp) w[sp] *= inv;
+        if (lane < ns) wts[g * ns + lane] = w0 * inv;
+        if (lane + 64 < ns) wts[g * ns + lane + 64] = w1 * inv;
     }
+    MV_ASTAMP(9);
     __syncthreads();
+    MV_ASTAMP(10);
     {
         const float* w = wts + mg * ns;
         f32x4_t acc_o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -421,6 +477,7 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
         *reinterpret_cast<f32x4_t*>(psum + (part * ITEMS + item) * 4) = acc_o;
     }
     __syncthreads();
+    MV_ASTAMP(6);
     if (threadIdx.x < ITEMS) {
         f32x4_t t = *reinterpret_cast<const f32x4_t*>(psum + item * 4);
 #pragma unroll
@@ -431,33 +488,57 @@ __global__ __launch_bounds__(kAT) void paged_attn_decode_kernel(AttnArgs a) {
         *reinterpret_cast<uint2*>(a.out + ((int64_t)b * a.hq + kvh * G + mg) * D + md4) = o2;
     }
     if (threadIdx.x == 0)  // leave the counter at zero for the next launch
-        __hip_atomic_store(a.arrive + bh, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.arrive + (int64_t)bh * kArriveStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    MV_ASTAMP(7);
 }
 
 // Second-launch form of the split merge (used when the arrival counters are unavailable or
 // switched off).  Same arithmetic and summation order as the in-kernel merge: PARTS interleaved
 // partial sums per output, added in order.
-template <int D, int G>
+template <int D, int G, int W>
 __global__ __launch_bounds__(D) void paged_attn_combine_kernel(const float* __restrict__ part_lse,
                                                                const float* __restrict__ part_o,
                                                                uint16_t* __restrict__ out,
                                                                int nsplit) {
     constexpr int ITEMS = G * D / 4;
-    constexpr int PARTS = kAT / ITEMS >= 1 ? kAT / ITEMS : 1;
+    constexpr int PARTS = W * 64 / ITEMS >= 1 ? W * 64 / ITEMS : 1;
     const int64_t bh = blockIdx.x;  // (b, query head)
     const int d = threadIdx.x;
     const float* lse = part_lse + bh * nsplit;
-    float mx = kNegBig;
-    for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, lse[s]);
-    float wsum = 0.f;
-    for (int s = 0; s < nsplit; ++s) wsum += __builtin_amdgcn_exp2f(lse[s] - mx);
-    const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+    __shared__ float wts[128];
     float total = 0.f;
-    for (int p = 0; p < PARTS; ++p) {
-        float o = 0.f;
-        for (int s = p; s < nsplit; s += PARTS)
-            o = __builtin_fmaf(__builtin_amdgcn_exp2f(lse[s] - mx) * inv, part_o[(bh * nsplit + s) * D + d], o);
-        total = p == 0 ? o : total + o;
+    if (nsplit <= 128) {  // same weight arithmetic as the in-kernel merge: one split per lane
+        if (threadIdx.x < 64) {
+            const int lane = threadIdx.x;
+            const float lse0 = lane < nsplit ? lse[lane] : kNegBig;
+            const float lse1 = lane + 64 < nsplit ? lse[lane + 64] : kNegBig;
+            const float mx = wave_max(fmaxf(lse0, lse1));
+            const float w0 = lane < nsplit ? __builtin_amdgcn_exp2f(lse0 - mx) : 0.f;
+            const float w1 = lane + 64 < nsplit ? __builtin_amdgcn_exp2f(lse1 - mx) : 0.f;
+            const float sum = wave_sum(w0 + w1);
+            const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+            wts[lane] = w0 * inv;
+            wts[lane + 64] = w1 * inv;
+        }
+        __syncthreads();
+        for (int p = 0; p < PARTS; ++p) {
+            float o = 0.f;
+            for (int s = p; s < nsplit; s += PARTS)
+                o = __builtin_fmaf(wts[s], part_o[(bh * nsplit + s) * D + d], o);
+            total = p == 0 ? o : total + o;
+        }
+    } else {
+        float mx = kNegBig;
+        for (int s = 0; s < nsplit; ++s) mx = fmaxf(mx, lse[s]);
+        float wsum = 0.f;
+        for (int s = 0; s < nsplit; ++s) wsum += __builtin_amdgcn_exp2f(lse[s] - mx);
+        const float inv = wsum > 0.f ? 1.0f / wsum : 0.f;
+        for (int p = 0; p < PARTS; ++p) {
+            float o = 0.f;
+            for (int s = p; s < nsplit; s += PARTS)
+                o = __builtin_fmaf(__builtin_amdgcn_exp2f(lse[s] - mx) * inv, part_o[(bh * nsplit + s) * D + d], o);
+            total = p == 0 ? o : total + o;
+        }
     }
     out[bh * D + d] = (uint16_t)f32_to_bf16_bits(total);
 }
@@ -466,7 +547,7 @@ __global__ __launch_bounds__(D) void paged_attn_combine_kernel(const float* __re
 // merging workgroup, so a launch needs no memset; calls that overlap on one GPU would share
 // them and must not (one decode stream per process is the model here).
 constexpr int kMaxArrive = 16384;
-static __device__ unsigned int g_arrive[kMaxArrive];
+static __device__ unsigned int g_arrive[kMaxArrive * kArriveStride];
 
 static unsigned int* arrive_counters() {
     static unsigned int* cached[64] = {nullptr};
@@ -480,13 +561,17 @@ static unsigned int* arrive_counters() {
     return cached[dev];
 }
 
-template <int D, int G>
-static int launch_decode(const AttnArgs& a, hipStream_t s) {
-    constexpr int NS = kAW * (64 / (D / 8));
+template <int D, int G, int W>
+static int launch_decode_w(const AttnArgs& a, hipStream_t s) {
+    constexpr int kAT = W * 64;
+    constexpr int NS = W * (64 / (D / 8));
     const size_t lds = (size_t)(2 * NS * G + NS * G * D) * sizeof(float);
+    static_assert((size_t)(2 * NS * G + NS * G * D) * sizeof(float) <= 160 * 1024 - 1024, "state merge fits LDS");
+    static_assert((size_t)(G * 128 + kAT * 4) * sizeof(float) <= (size_t)(2 * NS * G + NS * G * D) * sizeof(float),
+                  "split merge reuses the state arrays");
     static bool configured = false;
     if (lds > 64 * 1024 && !configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)paged_attn_decode_kernel<D, G>,
+        hipError_t e = hipFuncSetAttribute((const void*)paged_attn_decode_kernel<D, G, W>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) {
             set_last_hip_error(e);
@@ -494,13 +579,25 @@ static int launch_decode(const AttnArgs& a, hipStream_t s) {
         }
         configured = true;
     }
-    hipLaunchKernelGGL((paged_attn_decode_kernel<D, G>), dim3(a.bs * a.hkv * a.nsplit), dim3(kAT),
+    hipLaunchKernelGGL((paged_attn_decode_kernel<D, G, W>), dim3(a.bs * a.hkv * a.nsplit), dim3(kAT),
                        lds, s, a);
     int rc = check_launch();
     if (rc != MV_OK || a.nsplit == 1 || a.arrive != nullptr) return rc;
-    hipLaunchKernelGGL((paged_attn_combine_kernel<D, G>), dim3(a.bs * a.hq), dim3(D), 0, s,
+    hipLaunchKernelGGL((paged_attn_combine_kernel<D, G, W>), dim3(a.bs * a.hq), dim3(D), 0, s,
                        a.part_lse, a.part_o, a.out, a.nsplit);
     return check_launch();
+}
+
+static int g_tune_waves = 4;  // 0 = by grid size; 4 or 16 forces the narrow / wide workgroup
+
+// Wide workgroups (16 waves; 8 when G = 8 so that the per-row-group states still fit LDS) when the
+// launch leaves CUs idle anyway, the narrow one otherwise.
+template <int D, int G>
+static int launch_decode(const AttnArgs& a, hipStream_t s) {
+    constexpr int WIDE = G == 8 ? 8 : 16;
+    const int64_t grid = (int64_t)a.bs * a.hkv * a.nsplit;
+    const bool wide = g_tune_waves == 0 ? grid <= num_cus() : g_tune_waves != 4;
+    return wide ? launch_decode_w<D, G, WIDE>(a, s) : launch_decode_w<D, G, 4>(a, s);
 }
 
 template <int D>
@@ -516,7 +613,7 @@ static int dispatch_g(const AttnArgs& a, int g, hipStream_t s) {
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static int g_tune_inkernel_merge = 1;
-static int g_tune_target_blocks_x = 2;  // split count aims at this many workgroups per CU
+static int g_tune_target_blocks_x = 0;  // workgroups per CU the split count aims at (0 = built-in rule)
 
 }  // namespace mv
 
@@ -530,38 +627,60 @@ size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_split
 
 int mv_paged_attn_decode_pick_splits(int bs, int hkv, int ctx_hint) {
     if (bs <= 0 || hkv <= 0) return 1;
-    const int target = mv::g_tune_target_blocks_x * mv::num_cus();
-    int ns = (target + bs * hkv - 1) / (bs * hkv);
+    // Every split adds a fixed cost (state merge, partial write, arrival ticket) and the merging
+    // workgroup reads all of them, so the count aims at one workgroup per CU: measured on MI355X,
+    // bs=1 / 8 kv heads runs 12.3 us at 32 splits against 14.8 at 16 and 14.9 at 64 for ctx 4096,
+    // 16.8 / 21.6 / 17.4 us for ctx 8192; 8 sequences x 1 kv head at ctx 8192 run 23.3 us at 32
+    // splits, 29.7 at 16 and 37.6 at 64.  Large batches, where that rule gives a single split, are
+    // faster with two workgroups per CU (bs=32: 2 splits).
+    const int pairs = bs * hkv;
+    const int per_cu = mv::g_tune_target_blocks_x;  // 0 = the rule above
+    const int cus = mv::num_cus();
+    int ns;
+    if (per_cu > 0) {
+        ns = (per_cu * cus + pairs - 1) / pairs;
+    } else {
+        const int one = (cus + pairs - 1) / pairs, two = (2 * cus + pairs - 1) / pairs;
+        ns = two <= 4 ? two : one;
+    }
     if (ctx_hint > 0) {
         const int cap = ctx_hint / 64 > 1 ? ctx_hint / 64 : 1;  // at least 64 rows per split
         if (ns > cap) ns = cap;
     }
-    // Every split adds a fixed cost (state merge, partial write, arrival ticket) and the merging
-    // workgroup reads all of them: measured on MI355X, bs=1 / 8 kv heads / ctx 4096 runs 15.6 us
-    // at 16 splits against 22.8 us at 64, and bs=32 is fastest at 2.
-    // Longer contexts carry more splits at the same rows per split: 8 sequences x 1 kv head at
-    // ctx 8192 run 28.7 us at 16 splits and 24.2 us at 32.  Cap = one split per 256 rows, as a
-    // power of two, never below 16.
-    int cap16 = 16;
-    while (ctx_hint > 0 && cap16 * 2 * 256 <= ctx_hint && cap16 < 64) cap16 *= 2;
-    if (ns > cap16) ns = cap16;
+    if (ns > 64) ns = 64;
     if (ns < 1) ns = 1;
     return ns;
 }
 
 /* Experiment knobs: key 0 = merge splits inside the kernel (1) or in a second launch (0);
- * key 1 = workgroups per CU the automatic split count aims at. */
+ * key 1 = workgroups per CU the automatic split count aims at (0 = built-in rule); key 2 = waves per workgroup
+ * (0 = by grid size, 4 = narrow, 16 = wide). */
 int mv_paged_attn_tune(int key, int value) {
     if (key == 0 && (value == 0 || value == 1)) {
         mv::g_tune_inkernel_merge = value;
         return MV_OK;
     }
-    if (key == 1 && value >= 1 && value <= 8) {
+    if (key == 1 && value >= 0 && value <= 8) {
         mv::g_tune_target_blocks_x = value;
+        return MV_OK;
+    }
+    if (key == 2 && (value == 0 || value == 4 || value == 16)) {
+        mv::g_tune_waves = value;
         return MV_OK;
     }
     return MV_ERR_INVALID_ARG;
 }
+
+#ifdef MV_ATTN_STAMP
+int mv_debug_read_attn_stamps(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_astamp), bytes) == hipSuccess ? 0 : -3;
+}
+int mv_debug_clear_attn_stamps(void) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(mv::g_astamp)) != hipSuccess) return -3;
+    return hipMemset(p, 0, sizeof(unsigned long long) * 16 * 4096) == hipSuccess ? 0 : -3;
+}
+#endif
 
 int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, const void* v_new,
                          int64_t kv_stride_b, void* k_cache, void* v_cache, const void* rot_cos,

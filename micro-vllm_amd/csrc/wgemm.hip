@@ -33,6 +33,7 @@ static int g_tune_bpc = 0;      // workgroups per CU the grid is sized for (0 = 
 static int g_tune_waves = 0;    // waves per workgroup of the dot form: 8 or 16 (0 = planner)
 static int g_tune_sg = 0;       // strips per workgroup of the MFMA form: 1, 2 or 4 (0 = planner)
 static int g_tune_ksplit = 0;   // 0 = heuristic
+static int g_tune_contig = 0;   // dot form: consecutive tiles per wave
 
 enum { kProNone = 0, kProNorm = 1, kProAddNorm = 2 };
 
@@ -49,6 +50,7 @@ struct GemmArgs {
     int m, n, k;
     int nt, kt;      // strips, k-tiles per strip
     int ksplit, ktps;  // k-slices, k-tiles per slice
+    int contig;        // dot form: a wave's tiles are consecutive (1) or interleaved with the other waves' (0)
     int nunits;
     int flags;
     // fused input transform (dot form only): x <- rmsnorm(x [+ add_r]) * ln_w
@@ -60,7 +62,27 @@ struct GemmArgs {
     float eps;
     uint16_t* sum_out;          // kProAddNorm: bf16(x + add_r), written by workgroup 0
     int64_t ld_sum_out;
+#ifdef MV_WGEMM_STAMP
+    int stamp_slot;             // which of the 32 stamp records this launch writes
+#endif
 };
+
+#ifdef MV_WGEMM_STAMP
+// Phase stamps (build variant for tools/stamp_wgemm.py): the constant 100 MHz counter at up to
+// eight points of every workgroup of the last 32 launches, written by the workgroup's first thread.
+static __device__ unsigned long long g_wstamp[32 * 256 * 8];
+static int g_stamp_counter = 0;
+#define MV_WSTAMP(slot)                                                                          \
+    do {                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+        if (threadIdx.x == 0 && blockIdx.x < 256)                                                \
+            g_wstamp[((a.stamp_slot & 31) * 256 + blockIdx.x) * 8 + (slot)] =                    \
+                __builtin_amdgcn_s_memrealtime();                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                       \
+    } while (0)
+#else
+#define MV_WSTAMP(slot) do {} while (0)
+#endif
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
@@ -74,7 +96,7 @@ __device__ __forceinline__ float epilogue_value(const GemmArgs& a, float acc, in
 
 // ------------------------------------------------------------ M <= 4: dot form
 struct UnitCtx {
-    int nt, ks, kt0, ntile, nchunk, last;
+    int nt, ks, kt0, ntile, nchunk, last, wfirst;
     const uint4* wbase;
 };
 
@@ -92,25 +114,35 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
+    MV_WSTAMP(0);
 
+    const int tstride = a.contig ? 1 : GW;   // tiles between two consecutive tiles of a wave
+    const int wstride = tstride * 64;        // the same in 16-byte units
     auto setup = [&](int u) {
         UnitCtx c;
         c.nt = u / a.ksplit;
         c.ks = u - c.nt * a.ksplit;
         c.kt0 = c.ks * a.ktps;
         const int kt1 = min(a.kt, c.kt0 + a.ktps);
-        c.ntile = (kt1 - c.kt0 - wid + GW - 1) / GW;  // tiles of this wave (may be <= 0)
+        if (a.contig) {  // wave w owns tiles [w * tpw, (w + 1) * tpw) of the slice
+            const int tpw = (kt1 - c.kt0 + GW - 1) / GW;
+            c.wfirst = wid * tpw;
+            c.ntile = min(tpw, kt1 - c.kt0 - c.wfirst);
+        } else {         // wave w owns tiles w, w + GW, w + 2 GW, ...
+            c.wfirst = wid;
+            c.ntile = (kt1 - c.kt0 - wid + GW - 1) / GW;  // tiles of this wave (may be <= 0)
+        }
         c.nchunk = (c.ntile + U - 1) / U;
         c.last = max(c.ntile - 1, 0);
         // a wave without tiles still issues (clamped) loads: point it at the slice's first tile
-        c.wbase = a.w + ((int64_t)c.nt * a.kt + c.kt0 + (c.ntile > 0 ? wid : 0)) * 64 + lane;
+        c.wbase = a.w + ((int64_t)c.nt * a.kt + c.kt0 + (c.ntile > 0 ? c.wfirst : 0)) * 64 + lane;
         return c;
     };
     auto load = [&](uint4(&buf)[U], const UnitCtx& c, int chunk) {
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             const int t = min(chunk * U + i, c.last);  // clamp: always a valid address (chunk < 2^24)
-            buf[i] = ld16_nt(c.wbase + (int64_t)t * (GW * 64));
+            buf[i] = ld16_nt(c.wbase + (int64_t)t * wstride);
         }
     };
     auto compute = [&](const uint4(&buf)[U], const UnitCtx& c, int chunk, float(&acc)[M]) {
@@ -118,7 +150,7 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
         for (int i = 0; i < U; ++i) {
             const int t = chunk * U + i;
             // byte offset of this lane's 8 x values; out-of-range tiles read zeros
-            const int xoff = (t < c.ntile) ? ((c.kt0 + wid + t * GW) * 32 + q * 8) * 2 : -1;
+            const int xoff = (t < c.ntile) ? ((c.kt0 + c.wfirst + t * tstride) * 32 + q * 8) * 2 : -1;
 #pragma unroll
             for (int m = 0; m < M; ++m) {
                 const int off = (xoff < 0) ? zero_off : m * a.k * 2 + xoff;
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < U; ++i) {
         const int t = min(i, cur.last);  // indices past the end are clamped to the wave's last tile
-        const uint4 v = ld16_nt(cur.wbase + (int64_t)t * (GW * 64));
+        const uint4 v = ld16_nt(cur.wbase + (int64_t)t * wstride);
         bufA[i] = v;
         __builtin_amdgcn_sched_barrier(0);
     }
@@ -295,13 +327,14 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
         }
     }
     __syncthreads();
+    MV_WSTAMP(1);
 
     // Stage B goes out only now.  Requesting both stages before the input transform measured
     // slower on MI355X for every decode projection (O: 8.0 vs 7.3 us).
 #pragma unroll
     for (int i = U; i < 2 * U; ++i) {
         const int t = min(i, cur.last);
-        bufB[i - U] = ld16_nt(cur.wbase + (int64_t)t * (GW * 64));
+        bufB[i - U] = ld16_nt(cur.wbase + (int64_t)t * wstride);
         __builtin_amdgcn_sched_barrier(0);
     }
     // Chunks 0 and 1 of the current unit are in flight in bufA / bufB here and at the top of
@@ -320,6 +353,12 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
         for (int m = 0; m < M; ++m) acc[m] = 0.f;
 
         const int npair = (cur.nchunk + 1) >> 1;
+#ifdef MV_WGEMM_STAMP
+        if (u == (int)blockIdx.x && npair > 1) {
+            compute(bufA, cur, 0, acc);   // timing only: first stage landed (results are wrong)
+            MV_WSTAMP(2);
+        }
+#endif
         for (int p = 0; p < npair - 1; ++p) {
             compute(bufA, cur, 2 * p, acc);
             load(bufA, cur, 2 * p + 2);
@@ -336,6 +375,7 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
             compute(bufA, cur, cl, acc);
             compute(bufB, cur, cl + 1, acc);
         }
+        if (!more) MV_WSTAMP(3);
 
         // lanes r, r+16, r+32, r+48 hold the four k-quarters of row r
 #pragma unroll
@@ -376,6 +416,7 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
         u = un;
         cur = nxt;
     }
+    MV_WSTAMP(4);
 }
 
 // ------------------------------------------------------------ M > 4: MFMA form
@@ -576,6 +617,12 @@ static int launch_dot(const GemmArgs& a, int grid, hipStream_t s) {
         }
         configured = 160 * 1024;
     }
+#ifdef MV_WGEMM_STAMP
+    GemmArgs as = a;
+    as.stamp_slot = g_stamp_counter++;
+    hipLaunchKernelGGL((wgemm_dot_kernel<M, GW, U, PRO>), dim3(grid), dim3(GW * kWave), lds, s, as);
+    return check_launch();
+#endif
     hipLaunchKernelGGL((wgemm_dot_kernel<M, GW, U, PRO>), dim3(grid), dim3(GW * kWave), lds, s, a);
     return check_launch();
 }
@@ -674,6 +721,7 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
         }
     }
     a.ktps = a.kt / a.ksplit;
+    a.contig = g_tune_contig;
     const int sg = m > 4 ? mfma_strip_group((m + 15) / 16, a.nt) : 1;
     a.nunits = ((a.nt + sg - 1) / sg) * a.ksplit;
     a.flags = flags;
@@ -745,6 +793,10 @@ int mv_wgemm_tune(int key, int value) {
         mv::g_tune_ksplit = value;
         return MV_OK;
     }
+    if (key == 4 && (value == 0 || value == 1)) {
+        mv::g_tune_contig = value;
+        return MV_OK;
+    }
     return MV_ERR_INVALID_ARG;
 }
 
@@ -779,3 +831,9 @@ int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_
 }
 
 }  // extern "C"
+
+#ifdef MV_WGEMM_STAMP
+extern "C" int mv_debug_read_wgemm_stamps(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_wstamp), bytes) == hipSuccess ? 0 : -3;
+}
+#endif
