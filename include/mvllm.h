@@ -124,7 +124,8 @@ int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_
  * key 0 = workgroups per CU the grid is sized for (1..8; 0 = planner, the default);
  * key 1 = forced number of k-slices per strip (0 = pick automatically);
  * key 2 = waves per workgroup of the M <= 4 kernel (8 or 16; 0 = planner);
- * key 3 = strips a workgroup of the M > 4 kernel multiplies together (1, 2, 4; 0 = planner). */
+ * key 3 = strips a workgroup of the M > 4 kernel multiplies together (1, 2, 4; 0 = planner);
+ * key 4 = tiles of a wave of the M <= 4 kernel consecutive (1) or interleaved (0, the default). */
 int mv_wgemm_tune(int key, int value);
 
 /* y[M,N] = x[M,K] . W^T for many rows (prefill) on the matrix cores, reading the same tile image
@@ -143,7 +144,7 @@ size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_split
 
 /* How many KV splits the library would pick for this shape (ctx_hint = typical
  * context length; <= 0 means unknown). */
-int mv_paged_attn_decode_pick_splits(int bs, int hkv, int ctx_hint);
+int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint);
 
 /* Experiment knobs (no counterpart in the reference): key 0 = merge the KV splits inside the
  * attention kernel (1, default) or in a second launch (0); key 1 = workgroups per CU the

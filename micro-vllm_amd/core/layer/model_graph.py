@@ -184,14 +184,14 @@ class ModelGraphRunner:
         ns = self._num_splits.get(bs)
         if ns is None:
             ctx = cache_manager._block_table_buffer.shape[1] * cache_manager.block_size
-            ns = nv.lib().mv_paged_attn_decode_pick_splits(bs, self.kv_num_heads, ctx)
+            ns = nv.lib().mv_paged_attn_decode_pick_splits(bs, self.kv_num_heads, self.head_size, ctx)
             self._num_splits[bs] = ns
             if self._attn_ws is None:
                 # sized once for every batch size: captured graphs keep this pointer
                 L = nv.lib()
                 need = max(L.mv_paged_attn_decode_workspace_bytes(
                     b, self.num_heads, self.head_size,
-                    max(L.mv_paged_attn_decode_pick_splits(b, self.kv_num_heads, ctx), 2))
+                    max(L.mv_paged_attn_decode_pick_splits(b, self.kv_num_heads, self.head_size, ctx), 2))
                     for b in range(1, self.max_bs + 1))
                 self._attn_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
         return ns

@@ -117,7 +117,7 @@ def paged_attn_decode(q, k_new, v_new, k_cache, v_cache, cache_seqlens, block_ta
     assert block_table.stride(1) == 1 and cache_seqlens.is_contiguous()
     L = nv.lib()
     if num_splits <= 0:
-        num_splits = L.mv_paged_attn_decode_pick_splits(B, Hkv, block_table.shape[1] * page)
+        num_splits = L.mv_paged_attn_decode_pick_splits(B, Hkv, D, block_table.shape[1] * page)
     if out is None:
         out = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=q.device)
     assert out.is_contiguous() and out.shape == (B, Hq, D)

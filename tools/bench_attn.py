@@ -21,7 +21,7 @@ def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20):
     out = torch.empty(bs, hq, d, dtype=torch.bfloat16, device=dev)
     L = nv.lib()
     if splits <= 0:
-        splits = L.mv_paged_attn_decode_pick_splits(bs, hkv, pages * 256)
+        splits = L.mv_paged_attn_decode_pick_splits(bs, hkv, d, pages * 256)
     ws = torch.zeros(L.mv_paged_attn_decode_workspace_bytes(bs, hq, d, max(splits, 2)) // 4 + 4, dtype=torch.float32, device=dev)
     def one():
         for li in range(layers):

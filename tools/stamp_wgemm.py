@@ -71,6 +71,8 @@ for idx in order:
         if len(col):
             us = (col - t0) / 100
             row[nm] = (us.min(), np.median(us), us.max())
+    row["exit_by_xcd"] = [float(np.mean((rec[have, 4] - t0)[np.arange(256)[have] % 8 == x]) / 100) for x in range(8)]
+    row["exit_all"] = (rec[:, 4] - t0) / 100
     agg.setdefault(kind, []).append(row)
     prev_end = end
 for kind in names:
@@ -81,3 +83,9 @@ for kind in names:
         vals = np.array([r[nm] for r in rows if nm in r])
         if len(vals):
             print(f"    {nm:12s} min {vals[:,0].mean():6.2f}  median {vals[:,1].mean():6.2f}  max {vals[:,2].mean():6.2f}")
+    print("    mean exit by blockIdx %% 8: " + " ".join("%.2f" % np.mean([r["exit_by_xcd"][x] for r in rows]) for x in range(8)))
+    ex = np.array([r["exit_all"] for r in rows])          # [launch, block]
+    per_block = ex.mean(axis=0)
+    print("    exit averaged over launches, per block: min %.2f max %.2f; blocks 0-7 of each 64: %s" % (
+        per_block.min(), per_block.max(), " ".join("%.1f" % per_block[i] for i in (0, 1, 2, 3, 64, 65, 128, 129))))
+    print("    spread within one launch (max - mean): %.2f us" % np.mean(ex.max(axis=1) - ex.mean(axis=1)))
