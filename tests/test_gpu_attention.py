@@ -198,3 +198,33 @@ def test_in_kernel_merge_equals_second_kernel_merge(mv):
     for splits, lst in outs.items():
         assert torch.equal(lst[0], lst[1]) and torch.equal(lst[0], lst[2]), splits
         check_output(lst[0], case, what=f"merge splits={splits}")
+
+
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 2), (64, 8, 2)])
+def test_slots_that_do_not_count_may_hold_anything(mv, D, Hq, Hkv):
+    """The kernel requests the first rows of every split before it knows the sequence length, so it
+    reads slots at and past the length and pages no block table points to.  Whatever they hold
+    (NaN, Inf: a fresh cache is uninitialised memory) must not reach the output: same bits as with a
+    clean cache, for every split count."""
+    ctxs = [0, 1, 63, 64, 65, 300, 1000]
+    page = 256
+    case = make_case(len(ctxs), Hq, Hkv, D, page, ctxs, seed=91, pad_cols=3)
+    poison = torch.tensor([float("nan"), float("inf"), float("-inf")]).to(torch.bfloat16)
+    dirty = {k: v.clone() if torch.is_tensor(v) else v for k, v in case.items()}
+    used = torch.zeros(case["k_cache"].shape[0], page, dtype=torch.bool)
+    for b, c in enumerate(ctxs):
+        for t in range(c + 1):  # keys 0..c-1 are cached, slot c receives the new key
+            used[int(case["bt"][b, t // page]), t % page] = True
+    for name in ("k_cache", "v_cache"):
+        t = dirty[name]
+        fill = poison[torch.arange(t.numel()) % 3].reshape(t.shape)
+        dirty[name] = torch.where(used[:, :, None, None], t, fill)
+    for splits in (1, 3, 8, 0):
+        clean, _, _, _ = run_both(case, splits)
+        got, _, (kc, vc), _ = run_both(dirty, splits)
+        assert bool(torch.isfinite(got.float()).all()), f"splits={splits}"
+        assert torch.equal(got, clean), f"splits={splits}"
+        # and nothing but the new key's slot was written
+        keep = ~used[:, :, None, None].expand_as(dirty["k_cache"])
+        assert torch.equal(kc.cpu().view(torch.int16)[keep], dirty["k_cache"].view(torch.int16)[keep])
+        assert torch.equal(vc.cpu().view(torch.int16)[keep], dirty["v_cache"].view(torch.int16)[keep])
