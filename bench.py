@@ -298,7 +298,7 @@ def main():
             mgr.append(sid)
         mgr.cache_batch_data(seq_ids, [pos] * bs)
         logits = runner.forward(ids, mgr, bs)
-        return greedy(logits, out=next_ids)
+        return runner.greedy_ids(logits)    # the argmax is the last kernel of the captured step
 
     def sync_all():
         torch.cuda.synchronize()

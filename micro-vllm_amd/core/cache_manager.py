@@ -70,20 +70,25 @@ class KVCacheManager:
         self.cache_seqlens = torch.tensor([1], dtype=torch.int32, device=self.device)
         self.max_tokens = max_tokens
         self.max_seq_blocks = (max_tokens + block_size - 1) // block_size
-        self._block_table_buffer = torch.full((max_batch_size, self.max_seq_blocks), -1,
-                                              dtype=torch.int32, device=device)
-        self._cache_seqlens_buffer = torch.zeros(max_batch_size, dtype=torch.int32, device=device)
-        # Pinned host staging for the per-step rewrite: one asynchronous copy per buffer instead
-        # of one per row.  The copies are stream-ordered behind earlier decode steps, so the host
+        # One int32 allocation [max_batch seqlens | max_batch x max_seq_blocks block table], so that
+        # the per-step rewrite of both is a single host-to-device copy.
+        W = self.max_seq_blocks
+        self._step_buf = torch.full((max_batch_size * (1 + W),), -1, dtype=torch.int32, device=device)
+        self._step_buf[:max_batch_size] = 0
+        self._cache_seqlens_buffer = self._step_buf[:max_batch_size]
+        self._block_table_buffer = self._step_buf[max_batch_size:].view(max_batch_size, W)
+        # Pinned host staging for the per-step rewrite: one asynchronous copy instead of one per row.  The copies are stream-ordered behind earlier decode steps, so the host
         # may be several steps ahead of the device; a small ring of staging buffers, each guarded
         # by an event recorded after its copy, keeps the host from overwriting bytes a queued
         # copy has not read yet.
         self._on_gpu = torch.cuda.is_available() and str(device).startswith("cuda")
         self._ring = 4 if self._on_gpu else 1
-        self._bt_host = [torch.full((max_batch_size, self.max_seq_blocks), -1, dtype=torch.int32,
-                                    pin_memory=self._on_gpu) for _ in range(self._ring)]
-        self._sl_host = [torch.zeros(max_batch_size, dtype=torch.int32, pin_memory=self._on_gpu)
-                         for _ in range(self._ring)]
+        self._step_host = [torch.full((max_batch_size * (1 + W),), -1, dtype=torch.int32,
+                                      pin_memory=self._on_gpu) for _ in range(self._ring)]
+        for h in self._step_host:
+            h[:max_batch_size] = 0
+        self._sl_host = [h[:max_batch_size] for h in self._step_host]
+        self._bt_host = [h[max_batch_size:].view(max_batch_size, W) for h in self._step_host]
         self._ring_events = [None] * self._ring
         self._ring_next = 0
 
@@ -161,8 +166,8 @@ class KVCacheManager:
                             f"{self.max_seq_blocks} wide (max_tokens={self.max_tokens})")
                     bt[i, :len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
             sl[:n] = torch.tensor(context_lens, dtype=torch.int32)
-            self._block_table_buffer[:n].copy_(bt[:n], non_blocking=True)
-            self._cache_seqlens_buffer[:n].copy_(sl[:n], non_blocking=True)
+            upto = self._cache_seqlens_buffer.numel() + n * self.max_seq_blocks
+            self._step_buf[:upto].copy_(self._step_host[slot][:upto], non_blocking=True)
             if self._on_gpu:
                 ev = self._ring_events[slot] or torch.cuda.Event()
                 ev.record()

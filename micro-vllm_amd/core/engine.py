@@ -195,7 +195,8 @@ class InferenceEngine:
         self.cache_manager.cache_batch_data([s.seq_id for s in batch], [s.current_position for s in batch])
         logits = self.graph_runner.forward(input_ids, self.cache_manager, batch_size)
         if rank0():
-            next_tokens = self._sample(logits, temps, topp, 50)
+            ids = self.graph_runner.greedy_ids(logits) if bool((temps <= 0).all()) else None
+            next_tokens = ids.tolist() if ids is not None else self._sample(logits, temps, topp, 50)
             for i, seq in enumerate(batch):
                 seq._next_token = next_tokens[i]
 

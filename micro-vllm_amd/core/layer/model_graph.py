@@ -26,6 +26,7 @@ from ...kernel.linear import StreamedWeight, add_, embedding, gemm_workspace, wg
 from ...kernel.rmsnorm_add import rmsnorm_
 from ...kernel.rmsnorm_residual import rmsnorm_residual_gemm
 from ...kernel.swiglu import swiglu_gemm
+from .sampler import greedy
 
 logger = logging.getLogger(__name__)
 
@@ -159,6 +160,9 @@ class ModelGraphRunner:
         o_dim = _b.attn._o.shape[1]
         self._input_ids = torch.zeros(max_b, dtype=torch.long, device=dev)
         self._logits = torch.empty(max_b, self.vocab_size, dtype=dt, device=dev)
+        # argmax of every row of the last decode's logits: part of the captured step, so greedy
+        # decoding needs no launch of its own after the graph
+        self._greedy = torch.zeros(max_b, dtype=torch.long, device=dev)
         self._hidden0 = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
         self._normed = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
         self._qkv = torch.empty(max_b, qkv_dim, dtype=dt, device=dev)
@@ -302,10 +306,20 @@ class ModelGraphRunner:
             pend = None
             for layer_idx in range(self.num_layers):
                 h, pend = self._layer_norm_fused(h, pend, layer_idx, bs, cache_manager)
-            return self._head(h, bs, pend=pend)
-        for layer_idx in range(self.num_layers):
-            h = self._layer(h, layer_idx, bs, cache_manager)
-        return self._head(h, bs)
+            logits = self._head(h, bs, pend=pend)
+        else:
+            for layer_idx in range(self.num_layers):
+                h = self._layer(h, layer_idx, bs, cache_manager)
+            logits = self._head(h, bs)
+        greedy(logits, out=self._greedy)
+        return logits
+
+    def greedy_ids(self, logits: torch.Tensor):
+        """Row-wise argmax of `logits` if they are what the last decode returned (then it is already
+        there), else None."""
+        if logits.data_ptr() == self._logits.data_ptr() and logits.shape[1] == self.vocab_size:
+            return self._greedy[:logits.shape[0]]
+        return None
 
     def capture(self, cache_manager, batch_sizes: List[int] = [1, 2, 4, 8, 16, 32], warmup: int = 2):
         """Capture one graph per batch size.  The static block-table / seqlens buffers are read

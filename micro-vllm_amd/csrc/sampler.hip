@@ -55,6 +55,105 @@ __global__ __launch_bounds__(kAmThreads) void argmax_kernel(const uint16_t* __re
     }
 }
 
+// Few rows: one workgroup per row would leave the chip idle and read a 128k-entry row through a
+// single CU (about 15 us).  The row is cut into parts, one workgroup each; partial results go to a
+// fixed scratch array with write-through stores, and the workgroup that draws the last arrival
+// ticket of a row merges them.  The merge is a maximum under a total order (value, then lowest
+// index), so the result does not depend on arrival order.
+constexpr int kAmPartThreads = 256;
+constexpr int kAmMaxParts = 64;
+constexpr int kAmMaxRows = 64;
+static __device__ float g_am_val[kAmMaxRows * kAmMaxParts];
+static __device__ int g_am_idx[kAmMaxRows * kAmMaxParts];
+static __device__ unsigned int g_am_ticket[kAmMaxRows * 64];  // 256 bytes apart; zero between launches
+
+struct AmScratch {
+    float* val;
+    int* idx;
+    unsigned int* ticket;
+};
+
+__global__ __launch_bounds__(kAmPartThreads) void argmax_parts_kernel(const uint16_t* __restrict__ logits,
+                                                                      int64_t ld, int n, int parts,
+                                                                      int vec_per_part, AmScratch sc,
+                                                                      int64_t* __restrict__ ids) {
+    __shared__ float sv[kAmPartThreads / 64];
+    __shared__ int si[kAmPartThreads / 64];
+    __shared__ int is_last;
+    const int rowi = blockIdx.x / parts, part = blockIdx.x - rowi * parts;
+    const uint16_t* row = logits + (int64_t)rowi * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    const int nvec = n >> 3;
+    const int c0 = part * vec_per_part, c1 = min(nvec, c0 + vec_per_part);
+    for (int c = c0 + threadIdx.x; c < c1; c += kAmPartThreads) {
+        const uint4 v = ld16(row + c * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            amax_merge(best, bi, bf16_lo(w[j]), c * 8 + 2 * j);
+            amax_merge(best, bi, bf16_hi(w[j]), c * 8 + 2 * j + 1);
+        }
+    }
+    if (part == parts - 1)
+        for (int c = (nvec << 3) + threadIdx.x; c < n; c += kAmPartThreads)
+            amax_merge(best, bi, bf16_bits_to_f32(row[c]), c);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        amax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (lane == 0) {
+        sv[wid] = best;
+        si[wid] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kAmPartThreads / 64; ++w) amax_merge(best, bi, sv[w], si[w]);
+        const int slot = rowi * kAmMaxParts + part;
+        __hip_atomic_store(reinterpret_cast<unsigned int*>(sc.val + slot), __float_as_uint(best),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(sc.idx + slot, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // both stores have left before the ticket
+        const unsigned old = __hip_atomic_fetch_add(sc.ticket + rowi * 64, 1u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == (unsigned)parts - 1u;
+        if (is_last)  // back to zero for the next launch; nobody else touches it in this one
+            __hip_atomic_store(sc.ticket + rowi * 64, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last || threadIdx.x >= 64) return;
+    best = -INFINITY;
+    bi = 0x7fffffff;
+    if (lane < parts) {
+        const int slot = rowi * kAmMaxParts + lane;
+        best = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(sc.val + slot),
+                                                 __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        bi = __hip_atomic_load(sc.idx + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+        amax_merge(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+    if (lane == 0) ids[rowi] = bi == 0x7fffffff ? 0 : bi;  // all-NaN row: index 0
+}
+
+static bool am_scratch(AmScratch& sc) {
+    static AmScratch cached[64];
+    static bool have[64] = {false};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (!have[dev]) {
+        void *v = nullptr, *i = nullptr, *t = nullptr;
+        if (hipGetSymbolAddress(&v, HIP_SYMBOL(g_am_val)) != hipSuccess ||
+            hipGetSymbolAddress(&i, HIP_SYMBOL(g_am_idx)) != hipSuccess ||
+            hipGetSymbolAddress(&t, HIP_SYMBOL(g_am_ticket)) != hipSuccess)
+            return false;
+        cached[dev] = AmScratch{(float*)v, (int*)i, (unsigned int*)t};
+        have[dev] = true;
+    }
+    sc = cached[dev];
+    return true;
+}
+
 // ---------------------------------------------------------------- top-k / top-p sampling
 constexpr int kSmThreads = 1024;
 constexpr int kSmMaxK = 1024;
@@ -277,6 +376,24 @@ extern "C" int mv_argmax(const void* logits, int64_t ld, int rows, int n, int64_
     if (rows == 0 && n > 0) return MV_OK;
     if (!logits || !ids || rows < 0 || n <= 0 || ld < n) return MV_ERR_INVALID_ARG;
     if (!mv::aligned16(logits) || (ld % 8) != 0) return MV_ERR_INVALID_ARG;
+    // few long rows: several workgroups per row (calls that overlap on one GPU would share the
+    // scratch and must not - one decode stream per process is the model here)
+    const int nvec = n >> 3;
+    mv::AmScratch sc;
+    if (rows <= mv::kAmMaxRows && rows * 8 <= mv::num_cus() && nvec >= 4 * mv::kAmPartThreads &&
+        mv::am_scratch(sc)) {
+        int parts = mv::num_cus() / (2 * rows);
+        if (parts > mv::kAmMaxParts) parts = mv::kAmMaxParts;
+        const int most = nvec / mv::kAmPartThreads;  // at least one 16-byte load per thread
+        if (parts > most) parts = most;
+        if (parts >= 2) {
+            const int vec_per_part = (nvec + parts - 1) / parts;
+            hipLaunchKernelGGL(mv::argmax_parts_kernel, dim3(rows * parts), dim3(mv::kAmPartThreads), 0,
+                               (hipStream_t)stream, (const uint16_t*)logits, ld, n, parts, vec_per_part,
+                               sc, ids);
+            return mv::check_launch();
+        }
+    }
     hipLaunchKernelGGL(mv::argmax_kernel, dim3(rows), dim3(mv::kAmThreads), 0, (hipStream_t)stream,
                        (const uint16_t*)logits, ld, n, ids);
     return mv::check_launch();

@@ -51,3 +51,33 @@ def test_sampler_class_uses_device_kernel_and_respects_top_k(mv):
     top10 = logits.float().cpu().topk(10, dim=-1).indices
     assert all(int(picks[r]) in top10[r].tolist() for r in range(64))
     assert len(set(picks.tolist())) > 8          # actually random across rows
+
+
+@pytest.mark.parametrize("rows,v", [(1, 128256), (1, 32000), (2, 151936), (4, 128256), (1, 8200),
+                                    (1, 2048), (33, 32000), (40, 128256)])
+def test_greedy_is_first_maximum(mv, rows, v):
+    """mv_argmax: index of the largest logit, lowest index on ties, NaN never wins; the few-row
+    form (several workgroups per row, merged by the last to arrive) and the one-workgroup-per-row
+    form must agree with torch.  Bit exact (index work).  Called twice: the arrival tickets of the
+    first call must be back at zero for the second."""
+    from micro_vllm_amd.core.layer.sampler import greedy
+
+    g = torch.Generator().manual_seed(rows * 7 + v)
+    x = torch.randn(rows, v, generator=g).to(torch.bfloat16)
+    for r in range(rows):                      # ties for the maximum, scattered over the row
+        top = x[r].float().max().item()
+        idx = torch.randint(0, v, (5,), generator=g)
+        x[r, idx] = top
+    x[0, v - 1] = float("nan")
+    x[0, 0] = float("nan")
+    want = torch.where(torch.isnan(x.float()), torch.tensor(float("-inf")), x.float())
+    want = torch.stack([(row == row.max()).nonzero()[0, 0] for row in want])
+    xd = x.to("cuda")
+    for _ in range(2):
+        got = greedy(xd)
+        assert got.dtype == torch.long and torch.equal(got.cpu(), want)
+    # the maximum in the last, shorter part and in the scalar tail (v not a multiple of 8 is rejected
+    # by the vector path's callers; a multiple of 8 that does not divide into equal parts is not)
+    y = torch.full((1, v), -3.0, dtype=torch.bfloat16)
+    y[0, v - 3] = 5.0
+    assert int(greedy(y.to("cuda")).item()) == v - 3
