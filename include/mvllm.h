@@ -148,7 +148,7 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint);
 
 /* Experiment knobs (no counterpart in the reference): key 0 = merge the KV splits inside the
  * attention kernel (1, default) or in a second launch (0); key 1 = workgroups per CU the
- * automatic split count aims at (default 2). */
+ * automatic split count aims at (1..8; 0 = the built-in rule, default). */
 int mv_paged_attn_tune(int key, int value);
 
 /* Single-token paged attention with in-kernel NeoX RoPE and KV append.

@@ -6,10 +6,8 @@
 // All G = Hq/Hkv query heads that share the kv head are scored against the row
 // while it is in registers (GQA reuse: KV bytes are read once per kv head).
 //
-// Work split: workgroup = (sequence b, kv head, kv split); its W waves interleave
-// over the split's rows (W = 4 when the launch has more workgroups than CUs; 16, or 8 for
-// G = 8, when it has fewer: with one workgroup per CU the rows of a split are then all
-// requested at once and the score arithmetic is spread over four times the waves).  Every 16-lane (D=128) / 8-lane (D=64) row group keeps
+// Work split: workgroup = (sequence b, kv head, kv split); its W = 4 waves interleave
+// over the split's rows.  Every 16-lane (D=128) / 8-lane (D=64) row group keeps
 // its own online-softmax state (m, l, acc[G][8]); states meet once in LDS at the
 // end.  Splits write normalised fp32 partials + log2-sum-exp with write-through stores
 // and take a ticket on a per-(b, kv head) arrival counter; the workgroup that draws the
@@ -104,8 +102,7 @@ template <int D, int G, int W>
 __global__ __launch_bounds__(W * 64) void paged_attn_decode_kernel(AttnArgs a) {
     constexpr int kAW = W;          // waves per workgroup
     constexpr int kAT = W * 64;     // threads per workgroup
-    constexpr bool WIDE = W > 4;    // 128 registers per lane: shorter stages, both requested up front
-    constexpr int kAC = WIDE ? 2 : 4;  // row loads per wave per pipeline stage
+    constexpr int kAC = 4;          // row loads per wave per pipeline stage
     constexpr int LPR = D / 8;      // lanes per row
     constexpr int RPI = 64 / LPR;   // rows per wave instruction
     constexpr int NS = kAW * RPI;   // softmax states per workgroup
@@ -611,16 +608,13 @@ static int launch_decode_w(const AttnArgs& a, hipStream_t s) {
     return check_launch();
 }
 
-static int g_tune_waves = 4;  // 0 = by grid size; 4 or 16 forces the narrow / wide workgroup
-
-// Wide workgroups (16 waves; 8 when G = 8 so that the per-row-group states still fit LDS) when the
-// launch leaves CUs idle anyway, the narrow one otherwise.
+// Four waves per workgroup.  Eight or sixteen (with one workgroup per CU, so that more waves share
+// the score arithmetic) were measured on MI355X at bs = 1: 11.8 us against 11.9 at ctx 4096,
+// 14.9 against 15.4 at ctx 8192 with eight; slower with sixteen (the state merge grows with the
+// number of row groups).
 template <int D, int G>
 static int launch_decode(const AttnArgs& a, hipStream_t s) {
-    constexpr int WIDE = G == 8 ? 8 : 16;
-    const int64_t grid = (int64_t)a.bs * a.hkv * a.nsplit;
-    const bool wide = g_tune_waves == 0 ? grid <= num_cus() : g_tune_waves != 4;
-    return wide ? launch_decode_w<D, G, WIDE>(a, s) : launch_decode_w<D, G, 4>(a, s);
+    return launch_decode_w<D, G, 4>(a, s);
 }
 
 template <int D>
@@ -678,8 +672,7 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint) {
 }
 
 /* Experiment knobs: key 0 = merge splits inside the kernel (1) or in a second launch (0);
- * key 1 = workgroups per CU the automatic split count aims at (0 = built-in rule); key 2 = waves per workgroup
- * (0 = by grid size, 4 = narrow, 16 = wide). */
+ * key 1 = workgroups per CU the automatic split count aims at (0 = built-in rule). */
 int mv_paged_attn_tune(int key, int value) {
     if (key == 0 && (value == 0 || value == 1)) {
         mv::g_tune_inkernel_merge = value;
@@ -687,10 +680,6 @@ int mv_paged_attn_tune(int key, int value) {
     }
     if (key == 1 && value >= 0 && value <= 8) {
         mv::g_tune_target_blocks_x = value;
-        return MV_OK;
-    }
-    if (key == 2 && (value == 0 || value == 4 || value == 16)) {
-        mv::g_tune_waves = value;
         return MV_OK;
     }
     return MV_ERR_INVALID_ARG;

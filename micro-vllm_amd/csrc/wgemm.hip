@@ -469,6 +469,8 @@ __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
                 for (int sI = 0; sI < SG; ++sI) wb[i][sI] = ld16_nt(wbase[sI] + (int64_t)t * (kGW * 64));
                 const int kcol = (ktw + t * kGW) * 32;
 #pragma unroll
+                // (with these requests removed the four Llama-3-8B projections at M = 32 take 90 us
+                // instead of 104: the x path costs about 13 %)
                 for (int b = 0; b < MB; ++b) xb[i][b] = ld16(xrow[b] + kcol);
             }
         };

@@ -27,8 +27,6 @@ cos, sin = rotary_tables(d, 16384, device=dev)
 out = torch.empty(bs, hq, d, dtype=torch.bfloat16, device=dev)
 L = nv.lib()
 L.mv_debug_read_attn_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
-if "--waves" in sys.argv:
-    assert L.mv_paged_attn_tune(2, int(sys.argv[sys.argv.index("--waves") + 1])) == 0
 ws = torch.zeros(L.mv_paged_attn_decode_workspace_bytes(bs, hq, d, max(splits, 2)) // 4 + 4, dtype=torch.float32, device=dev)
 flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 names = ["entry", "q/k ready", "rows absorbed", "partials issued", "stores drained", "ticket known", "merge summed", "end",
