@@ -352,46 +352,51 @@ __global__ __launch_bounds__(W * 64) void paged_attn_decode_kernel(AttnArgs a) {
         *reinterpret_cast<f32x4_t*>(dst + 4) = (f32x4_t){acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
     }
     __syncthreads();
-    // weights 2^(m_s - max) once per (state, head), written over st_m; one wave per head, one
-    // state per lane.  Head g's totals land in st_l[g] and st_l[G + g], both entries of its own
-    // states 0 and 1, which only this wave reads.
-    for (int g = wid; g < G; g += kAW) {
+    // One thread per (head, 4 consecutive d): it works out the weights 2^(m_s - max) of its head's
+    // NS states itself (every thread of a head repeats that, which is cheaper than a phase and a
+    // barrier of its own), then adds the states in order.
+    if (threadIdx.x < G * D / 4) {
+        const int g = threadIdx.x / (D / 4), d4 = (threadIdx.x - g * (D / 4)) * 4;
         float mx = kNegBig;
-        for (int s = lane; s < NS; s += 64) mx = fmaxf(mx, st_m[s * G + g]);
-        mx = wave_max(mx);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mx = fmaxf(mx, st_m[s * G + g]);
         float lt = 0.f;
-        for (int s = lane; s < NS; s += 64) {
+        f32x4_t at = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
             const float w = __builtin_amdgcn_exp2f(st_m[s * G + g] - mx);
             lt = __builtin_fmaf(st_l[s * G + g], w, lt);
-            st_m[s * G + g] = w;
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(st_acc + (int64_t)(s * G + g) * D + d4);
+            at[0] = __builtin_fmaf(v[0], w, at[0]);
+            at[1] = __builtin_fmaf(v[1], w, at[1]);
+            at[2] = __builtin_fmaf(v[2], w, at[2]);
+            at[3] = __builtin_fmaf(v[3], w, at[3]);
         }
-        lt = wave_sum(lt);
-        if (lane == 0) {
-            st_l[g] = lt;            // total normaliser of head g
-            st_l[G + g] = mx;        // its reference maximum
-        }
-    }
-    __syncthreads();
-    for (int o = threadIdx.x; o < G * D; o += kAT) {
-        const int g = o / D, d = o - g * D;
-        const float lt = st_l[g], mx = st_l[G + g];
-        float at = 0.f;
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-            at = __builtin_fmaf(st_acc[(int64_t)(s * G + g) * D + d], st_m[s * G + g], at);
         const int hq = kvh * G + g;
-        const float val = lt > 0.f ? at / lt : 0.f;
+        f32x4_t val = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (lt > 0.f) {
+            val[0] = at[0] / lt;
+            val[1] = at[1] / lt;
+            val[2] = at[2] / lt;
+            val[3] = at[3] / lt;
+        }
         if (a.nsplit == 1) {
-            a.out[((int64_t)b * a.hq + hq) * D + d] = (uint16_t)f32_to_bf16_bits(val);
+            uint2 o2;
+            o2.x = pack_bf16x2(val[0], val[1]);
+            o2.y = pack_bf16x2(val[2], val[3]);
+            *reinterpret_cast<uint2*>(a.out + ((int64_t)b * a.hq + hq) * D + d4) = o2;
         } else {
             // write-through (sc1) stores: visible to the merging workgroup without a release fence
-            const int64_t pi = ((int64_t)b * a.hq + hq) * a.nsplit + split;
-            __hip_atomic_store(reinterpret_cast<unsigned int*>(a.part_o + pi * D + d),
-                               __float_as_uint(val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (d == 0)
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                a.part_o + ((int64_t)b * a.hq + kvh * G) * a.nsplit * D, 0, G * a.nsplit * D * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, val), prs,
+                                                   ((g * a.nsplit + split) * D + d4) * 4, 0, 16 /*sc1*/);
+            if (d4 == 0) {
+                const int64_t pi = ((int64_t)b * a.hq + hq) * a.nsplit + split;
                 __hip_atomic_store(reinterpret_cast<unsigned int*>(a.part_lse + pi),
                                    __float_as_uint(lt > 0.f ? mx + __builtin_amdgcn_logf(lt) : kNegBig),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
     }
     MV_ASTAMP(3);
