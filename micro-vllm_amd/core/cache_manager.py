@@ -156,7 +156,8 @@ class KVCacheManager:
             if self._ring_events[slot] is not None:
                 self._ring_events[slot].synchronize()
             bt, sl = self._bt_host[slot], self._sl_host[slot]
-            bt[:n].fill_(-1)
+            bt_np = bt.numpy()   # a view: plain integer stores instead of one tensor per row
+            bt_np[:n] = -1
             for i, sid in enumerate(seq_ids):
                 blocks = self._blocks.get(sid, [])
                 if blocks:
@@ -164,8 +165,8 @@ class KVCacheManager:
                         raise RuntimeError(
                             f"sequence {sid} spans {len(blocks)} blocks but the block table is "
                             f"{self.max_seq_blocks} wide (max_tokens={self.max_tokens})")
-                    bt[i, :len(blocks)] = torch.tensor(blocks, dtype=torch.int32)
-            sl[:n] = torch.tensor(context_lens, dtype=torch.int32)
+                    bt_np[i, :len(blocks)] = blocks
+            sl.numpy()[:n] = context_lens
             upto = self._cache_seqlens_buffer.numel() + n * self.max_seq_blocks
             self._step_buf[:upto].copy_(self._step_host[slot][:upto], non_blocking=True)
             if self._on_gpu:

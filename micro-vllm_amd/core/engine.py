@@ -80,6 +80,10 @@ class InferenceEngine:
         self.scheduler = Scheduler(max_batch_size, max_prefill_tokens, tokenizer, prefill_timeout)
         self.sampler = Sampler()
 
+        # The synchronous token read-back at the end of a step means a staging row is never
+        # overwritten before its copy has run; two rows keep that true if a caller pipelines.
+        self._ids_host = [torch.zeros(max_batch_size, dtype=torch.long, pin_memory=True) for _ in range(2)]
+        self._ids_slot = 0
         self.eos_token_id = getattr(tokenizer, "eos_token_id", None)
         self.stream_callbacks = {}
         self.max_position = getattr(cfg, "max_position_embeddings", 4096)
@@ -186,17 +190,27 @@ class InferenceEngine:
         for seq in batch:
             first.append(seq.seq_id not in seen)
             seen.add(seq.seq_id)
-        input_ids = torch.tensor([seq.get_next_input_ids() for seq in batch], device=device).squeeze(1)
-        temps = torch.tensor([seq.temperature for seq in batch], device=device)
-        topp = torch.tensor([seq.top_p for seq in batch], device=device)
+        # one pinned staging row per step in flight; the copy into the runner's static input buffer is
+        # the only host-to-device traffic besides the block table
+        ids_host = self._ids_host[self._ids_slot]
+        self._ids_slot = (self._ids_slot + 1) % len(self._ids_host)
+        for i, seq in enumerate(batch):
+            ids_host[i] = seq.get_next_input_ids()[0]
+        input_ids = ids_host[:batch_size].to(device, non_blocking=True)
+        all_greedy = all(seq.temperature <= 0 for seq in batch)
         for i, seq in enumerate(batch):
             if first[i] and self.cache_manager.append(seq.seq_id) == -1:
                 raise RuntimeError("OOM")
         self.cache_manager.cache_batch_data([s.seq_id for s in batch], [s.current_position for s in batch])
         logits = self.graph_runner.forward(input_ids, self.cache_manager, batch_size)
         if rank0():
-            ids = self.graph_runner.greedy_ids(logits) if bool((temps <= 0).all()) else None
-            next_tokens = ids.tolist() if ids is not None else self._sample(logits, temps, topp, 50)
+            ids = self.graph_runner.greedy_ids(logits) if all_greedy else None
+            if ids is not None:
+                next_tokens = ids.tolist()
+            else:
+                temps = torch.tensor([seq.temperature for seq in batch], device=device)
+                topp = torch.tensor([seq.top_p for seq in batch], device=device)
+                next_tokens = self._sample(logits, temps, topp, 50)
             for i, seq in enumerate(batch):
                 seq._next_token = next_tokens[i]
 

@@ -295,20 +295,33 @@ __global__ __launch_bounds__(W * 64) void paged_attn_decode_kernel(AttnArgs a) {
     };
 
     MV_ASTAMP(1);
-    for (int c = 0; c < nchunk; c += 2) {  // rows of chunks c, c + 1 and page ids of c + 2, c + 3 are in flight
+    // Rows of chunks c, c + 1 and page ids of c + 2, c + 3 are in flight at the top of every pass.
+    // The steady state has no branch around a request, so the compiler's wait counts are exact
+    // (with the requests under `if`s every wait also covered the other stage, and a long split
+    // had barely one stage in flight); the last three chunks at most are handled after it.
+    int c = 0;
+    for (; c + 3 < nchunk; c += 2) {
         absorb(kA, vA, okA);
 #ifdef MV_ATTN_STAMP
         if (c == 0) MV_ASTAMP(8);
 #endif
-        if (c + 2 < nchunk) {
-            load_rows(kA, vA, okA, pgA, c + 2);
-            load_pages(pgA, c + 4);
-        }
+        // (the fences keep the scheduler from gathering both stages' arithmetic in front of
+        // both stages' requests, which would leave nothing in flight while it runs)
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(kA, vA, okA, pgA, c + 2);
+        load_pages(pgA, c + 4);
+        __builtin_amdgcn_sched_barrier(0);
+        absorb(kB, vB, okB);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(kB, vB, okB, pgB, c + 3);
+        load_pages(pgB, c + 5);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c < nchunk) {
+        absorb(kA, vA, okA);
+        if (c + 2 < nchunk) load_rows(kA, vA, okA, pgA, c + 2);
         if (c + 1 < nchunk) absorb(kB, vB, okB);
-        if (c + 3 < nchunk) {
-            load_rows(kB, vB, okB, pgB, c + 3);
-            load_pages(pgB, c + 5);
-        }
+        if (c + 2 < nchunk) absorb(kA, vA, okA);
     }
 
     // ---- the new row (held in registers; never read back from the cache) --------
