@@ -131,7 +131,8 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
 #pragma unroll
         for (int t = 0; t < kPMT; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // weight fragments: a ring of three k-tiles, each refilled right after its MFMAs are issued
+    // weight fragments: a ring of three k-tiles; a slot is refilled (two k-tiles ahead) at the start
+    // of the k-tile after the one that used it
     uint4 wA[kPNT], wB[kPNT], wC[kPNT];
     auto w_load = [&](uint4(&w)[kPNT], int kt) {
         const int ktc = min(kt, a.kt - 1);
@@ -147,7 +148,6 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     x_fetch(1, 1);
     w_load(wA, 0);
     w_load(wB, 1);
-    w_load(wC, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -158,11 +158,18 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     for (int t = 0; t < kPMT / 2; ++t) X0[t] = x_frag(0, t, 0);
 
     // one k-tile: (buf, kk) = where it lives; (nbuf, nkk) = the k-tile after it
-    auto ktile = [&](uint4(&w)[kPNT], bf16x8_t(&xc)[kPMT], bf16x8_t(&xn)[kPMT], int buf, int kk, int nbuf,
-                     int nkk, int kt_refill) {
+    // `w` = this k-tile's weight fragments; `wr` = the ring slot the previous k-tile used, refilled
+    // here, first thing, with the k-tile two ahead (left to itself the scheduler sinks these
+    // requests to the end of the stage, and the next stage then starts by waiting for them).
+    // `fetch_stage` >= 0: also request that stage of x, after the first half of the MFMAs.
+    auto ktile = [&](uint4(&w)[kPNT], uint4(&wr)[kPNT], bf16x8_t(&xc)[kPMT], bf16x8_t(&xn)[kPMT], int buf,
+                     int kk, int nbuf, int nkk, int kt_refill, int fetch_stage, int fetch_buf) {
         bf16x8_t wf[kPNT];
 #pragma unroll
         for (int i = 0; i < kPNT; ++i) wf[i] = __builtin_bit_cast(bf16x8_t, w[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        w_load(wr, kt_refill);
+        __builtin_amdgcn_sched_barrier(0);
         // (pinning this order with scheduling fences measured 3 % slower than letting the
         // scheduler interleave reads and MFMAs itself)
 #pragma unroll
@@ -172,6 +179,14 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < kPNT; ++i)
                 acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xc[t], acc[i][t], 0, 0, 0);
+        // The x requests are invisible to the compiler's request counting, so they go out behind
+        // the waits for this k-tile's weights: in front of them they would make those waits cover
+        // the previous refill as well.
+        if (fetch_stage >= 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            x_fetch(fetch_stage, fetch_buf);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int t = 0; t < kPMT / 2; ++t) xn[t] = x_frag(nbuf, t, nkk);
 #pragma unroll
@@ -179,27 +194,31 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < kPNT; ++i)
                 acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xc[t], acc[i][t], 0, 0, 0);
-        w_load(w, kt_refill);
     };
     // One stage: request stage s+2 of x (its buffer was last read in stage s-1), two k-tiles, wait
     // for this wave's part of stage s+2 (two weight refills were requested after it), barrier: the
     // next stage's later reads and the stage after's early reads both see complete data.
-    auto stage = [&](uint4(&w0)[kPNT], uint4(&w1)[kPNT], int s, int b0, int b1, int b2) {
+    auto stage = [&](uint4(&w0)[kPNT], uint4(&w1)[kPNT], uint4(&w2)[kPNT], int s, int b0, int b1, int b2) {
         MV_STAMP(0);
-        x_fetch(s + 2, b2);
-        ktile(w0, X0, X1, b0, 0, b0, 1, 2 * s + 3);
-        ktile(w1, X1, X0, b0, 1, b1, 0, 2 * s + 4);
+        ktile(w0, w2, X0, X1, b0, 0, b0, 1, 2 * s + 2, s + 2, b2);
+        ktile(w1, w0, X1, X0, b0, 1, b1, 0, 2 * s + 3, -1, 0);
         MV_STAMP(1);
-        wait_vmcnt<2 * kPNT>();
+        wait_vmcnt<kPNT>();   // only the second k-tile's refill was requested after the x stage
         MV_STAMP(2);
         __syncthreads();
         MV_STAMP(3);
     };
-    for (int s = 0; s < nstage; s += 3) {
-        stage(wA, wB, s, 0, 1, 2);
-        if (s + 1 < nstage) stage(wC, wA, s + 1, 1, 2, 0);
-        if (s + 2 < nstage) stage(wB, wC, s + 2, 2, 0, 1);
+    // three stages per pass and no branch inside the pass (a branch between stages makes the
+    // compiler wait for every outstanding request where the paths meet); the one or two stages
+    // left over follow
+    int s = 0;
+    for (; s + 2 < nstage; s += 3) {
+        stage(wA, wB, wC, s, 0, 1, 2);
+        stage(wC, wA, wB, s + 1, 1, 2, 0);
+        stage(wB, wC, wA, s + 2, 2, 0, 1);
     }
+    if (s < nstage) stage(wA, wB, wC, s, 0, 1, 2);
+    if (s + 1 < nstage) stage(wC, wA, wB, s + 1, 1, 2, 0);
 
     // acc[i][t][j] = C[n = 16 (nt0+i) + 4q + j][m = m0 + 16 t + r]
     const bool sw = (a.flags & MV_GEMM_SWIGLU) != 0, of32 = (a.flags & MV_GEMM_OUT_F32) != 0;
