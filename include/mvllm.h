@@ -120,6 +120,21 @@ int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_
                   void* y, int64_t ldy, int m, int n, int k, void* workspace,
                   size_t workspace_bytes, int flags, mv_stream_t stream);
 
+/* mv_wgemm with the norm kernel that FOLLOWS the projection folded into the output (any M <= 64,
+ * n <= 8192; the product goes through fp32 slabs in `workspace`, one launch sums them, applies
+ * the epilogue and normalises the row):
+ *   t = bf16(x @ W^T); t = bf16(t + bias); s = t + residual; y = bf16(s);
+ *   normed = bf16((float(y) * rrms) * ln_w), rrms = 1/sqrt(mean(s^2) + eps)
+ * i.e. matmul followed by rmsnorm_residual_gemm (core/layer/model_graph.py:171 then :213: the
+ * variance is taken from the unrounded s), or, with MV_NORM_VAR_FROM_ROUNDED, matmul + residual
+ * add followed by the next block's rmsnorm_ (:185, :219, :143: variance from y as stored).
+ * Bit-identical to mv_wgemm followed by mv_rmsnorm_residual / mv_rmsnorm. */
+size_t mv_wgemm_postnorm_workspace_bytes(int m, int n, int k);
+int mv_wgemm_postnorm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
+                      const void* residual, int64_t ld_res, void* y, int64_t ldy, const void* ln_w,
+                      float eps, void* normed, int64_t ld_normed, int norm_flags, int m, int n, int k,
+                      void* workspace, size_t workspace_bytes, mv_stream_t stream);
+
 /* Launch-shape knobs for experiments (no counterpart in the reference):
  * key 0 = workgroups per CU the grid is sized for (1..8; 0 = planner, the default);
  * key 1 = forced number of k-slices per strip (0 = pick automatically);

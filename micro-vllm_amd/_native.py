@@ -46,6 +46,8 @@ PROTOTYPES = {
     "mv_wgemm": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P, _Z, _I, _P]),
     "mv_wgemm_norm": (_I, [_P, _L, _P, _L, _P, _F, _P, _L, _I, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P,
                            _Z, _I, _P]),
+    "mv_wgemm_postnorm_workspace_bytes": (_Z, [_I, _I, _I]),
+    "mv_wgemm_postnorm": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _P, _F, _P, _L, _I, _I, _I, _I, _P, _Z, _P]),
     "mv_paged_attn_decode_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "mv_paged_attn_decode_pick_splits": (_I, [_I, _I, _I, _I]),
     "mv_paged_attn_tune": (_I, [_I, _I]),

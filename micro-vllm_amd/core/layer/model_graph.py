@@ -22,7 +22,8 @@ import torch
 from .. import parallel_config as pc
 from ..paged_attention import PagedAttention, paged_attn_decode
 from ... import _native as nv
-from ...kernel.linear import StreamedWeight, add_, embedding, gemm_workspace, wgemm, wgemm_norm
+from ...kernel.linear import (StreamedWeight, add_, embedding, gemm_workspace, wgemm, wgemm_norm,
+                              wgemm_postnorm)
 from ...kernel.rmsnorm_add import rmsnorm_
 from ...kernel.rmsnorm_residual import rmsnorm_residual_gemm
 from ...kernel.swiglu import swiglu_gemm
@@ -180,6 +181,8 @@ class ModelGraphRunner:
                   (self.hidden_dim, _b.mlp._d.k), (self.vocab_size, self.hidden_dim)]
         for n, k in shapes:
             need = max(need, L.mv_wgemm_workspace_bytes(max_b, n, k))
+        for k in (_b.attn._o.k, _b.mlp._d.k):  # projections whose slab reduction carries a norm
+            need = max(need, L.mv_wgemm_postnorm_workspace_bytes(max_b, self.hidden_dim, k))
         self._gemm_ws = gemm_workspace(dev, max(need, 16))
         self._attn_ws = None
 
@@ -307,12 +310,48 @@ class ModelGraphRunner:
             for layer_idx in range(self.num_layers):
                 h, pend = self._layer_norm_fused(h, pend, layer_idx, bs, cache_manager)
             logits = self._head(h, bs, pend=pend)
+        elif self.fused and self.world_size == 1:
+            logits = self._decode_batched(h, bs, cache_manager)
         else:
             for layer_idx in range(self.num_layers):
                 h = self._layer(h, layer_idx, bs, cache_manager)
             logits = self._head(h, bs)
         greedy(logits, out=self._greedy)
         return logits
+
+    def _decode_batched(self, h, bs, cache_manager):
+        """bs > 4 on one GPU: the norm that follows the O and the down projection rides on their
+        slab reduction (`wgemm_postnorm`), so a block is QKV, attention, O(+add+norm), gate/up,
+        down(+residual+next norm): five projections' worth of launches instead of ten.  Same
+        arithmetic, bit for bit, as `_layer` (model_graph.py:141-220 of the reference)."""
+        tr = self.model.transformer
+        blocks = tr.h
+        ws = self._gemm_ws
+        normed = self._normed[:bs]
+        rmsnorm_(h, blocks[0].ln_1.weight, normed, blocks[0].ln_1.eps)
+        for layer_idx in range(self.num_layers):
+            block = blocks[layer_idx]
+            wgemm(normed, block.attn._qkv_w, self._qkv[:bs], bias=block.attn._qkv_b, workspace=ws)
+            hq, hkv, d = self.num_heads, self.kv_num_heads, self.head_size
+            qkv = self._qkv[:bs]
+            k_cache, v_cache = cache_manager.get(layer_idx)
+            attn = paged_attn_decode(
+                qkv[:, :hq * d].unflatten(1, (hq, d)), qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)),
+                qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d)), k_cache, v_cache,
+                cache_manager._cache_seqlens_buffer[:bs], cache_manager._block_table_buffer[:bs],
+                self.attention._cos_pool, self.attention._sin_pool,
+                num_splits=self._splits_for(bs, cache_manager), out=self._attn[:bs],
+                workspace=self._attn_ws)
+            # residual <- bf16(attn @ Wo^T + h); normed <- rmsnorm(that sum, unrounded) * ln_2
+            wgemm_postnorm(attn.reshape(bs, -1), block.attn._o, self._residual[:bs], block.ln_2.weight,
+                           block.ln_2.eps, normed, residual=h, workspace=ws)
+            wgemm(normed, block.mlp._gu, self._swiglu_out[:bs], swiglu=True, workspace=ws)
+            # h <- bf16(act @ Wd^T + residual); normed <- rmsnorm(h) * (next block's ln_1 | ln_f)
+            nxt = blocks[layer_idx + 1].ln_1 if layer_idx + 1 < self.num_layers else tr.ln_f
+            wgemm_postnorm(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs], nxt.weight, nxt.eps,
+                           normed, residual=self._residual[:bs], var_from_rounded=True, workspace=ws)
+            h = self._mlp_out[:bs]
+        return wgemm(normed, self._lm_head, self._logits[:bs], workspace=ws)
 
     def greedy_ids(self, logits: torch.Tensor):
         """Row-wise argmax of `logits` if they are what the last decode returned (then it is already

@@ -62,6 +62,12 @@ struct GemmArgs {
     float eps;
     uint16_t* sum_out;          // kProAddNorm: bf16(x + add_r), written by workgroup 0
     int64_t ld_sum_out;
+    // output transform of the slab reduction: normed = rmsnorm(y) * post_ln_w next to y itself
+    const uint16_t* post_ln_w;
+    uint16_t* post_out;
+    int64_t ld_post;
+    float post_eps;
+    int post_var_from_rounded;  // variance from y as stored (bf16) instead of the unrounded t + residual
 #ifdef MV_WGEMM_STAMP
     int stamp_slot;             // which of the 32 stamp records this launch writes
 #endif
@@ -398,7 +404,7 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
 #pragma unroll
             for (int w8 = 0; w8 < GW; ++w8) s += red[(w8 * M + m) * 16 + rr];
             const int n = cur.nt * 16 + rr;
-            if (a.ksplit > 1) {
+            if (a.partial) {
                 a.partial[((int64_t)cur.ks * a.m + m) * a.n + n] = s;
             } else if (a.flags & MV_GEMM_OUT_F32) {
                 reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n] = s;
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
             if (m < a.m && nt < a.nt) {
                 const f32x4_t s = sum_at(l);
                 const int n0 = nt * 16 + qq * 4;
-                if (a.ksplit > 1) {
+                if (a.partial) {
                     *reinterpret_cast<f32x4_t*>(&a.partial[((int64_t)ks * a.m + m) * a.n + n0]) = s;
                 } else if (a.flags & MV_GEMM_OUT_F32) {
                     *reinterpret_cast<f32x4_t*>(
@@ -573,6 +579,80 @@ __global__ __launch_bounds__(256) void wgemm_finalize_kernel(GemmArgs a) {
         } else {
             reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + c] =
                 (uint16_t)f32_to_bf16_bits(epilogue_value(a, slab_sum(c), m, c));
+        }
+    }
+}
+
+// Slab reduction + output epilogue + RMSNorm of the result, one workgroup per row:
+//   t = bf16(sum of slabs); t = bf16(t + bias); s = t + residual (fp32); y = bf16(s);
+//   normed = bf16((float(y) * rrms) * ln_w),  rrms = 1 / sqrt(mean(s^2) + eps)
+// with the mean over the unrounded s (what add+RMSNorm after a projection computes) or, with
+// post_var_from_rounded, over y as stored (what RMSNorm of a stored hidden state computes).
+// Chunk assignment and summation order are those of the stand-alone norm kernels (256 threads,
+// stride 256, block_sum), so the fused and the separate path agree bit for bit.
+constexpr int kPostChunks = 4;  // 16-byte chunks of y a thread keeps: rows up to 8192 wide
+__global__ __launch_bounds__(256) void wgemm_finalize_norm_kernel(GemmArgs a) {
+    __shared__ float red[256 / 64];
+    const int m = blockIdx.x;
+    const int nvec = a.n >> 3;
+    uint4 keep[kPostChunks];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < kPostChunks; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < nvec) {
+            const int n0 = c * 8;
+            f32x4_t lo = (f32x4_t){0.f, 0.f, 0.f, 0.f}, hi = lo;
+            for (int ks = 0; ks < a.ksplit; ++ks) {
+                const float* p = a.partial + ((int64_t)ks * a.m + m) * a.n + n0;
+                lo += *reinterpret_cast<const f32x4_t*>(p);
+                hi += *reinterpret_cast<const f32x4_t*>(p + 4);
+            }
+            const float acc[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            uint4 bv = make_uint4(0, 0, 0, 0), rv = bv;
+            if (a.bias) bv = ld16(a.bias + n0);
+            if (a.residual) rv = ld16(a.residual + (int64_t)m * a.ld_res + n0);
+            const uint32_t b4[4] = {bv.x, bv.y, bv.z, bv.w}, r4[4] = {rv.x, rv.y, rv.z, rv.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float t0 = round_bf16(acc[2 * e]), t1 = round_bf16(acc[2 * e + 1]);
+                if (a.bias) {
+                    t0 = round_bf16(t0 + bf16_lo(b4[e]));
+                    t1 = round_bf16(t1 + bf16_hi(b4[e]));
+                }
+                float s0 = t0, s1 = t1;
+                if (a.residual) {
+                    s0 = t0 + bf16_lo(r4[e]);
+                    s1 = t1 + bf16_hi(r4[e]);
+                }
+                o[e] = pack_bf16x2(s0, s1);
+                if (a.post_var_from_rounded) {
+                    s0 = bf16_lo(o[e]);
+                    s1 = bf16_hi(o[e]);
+                }
+                ss += s0 * s0;
+                ss += s1 * s1;
+            }
+            keep[j] = make_uint4(o[0], o[1], o[2], o[3]);
+            st16(reinterpret_cast<uint16_t*>(a.y) + (int64_t)m * a.ldy + n0, keep[j]);
+        }
+    }
+    const float total = block_sum(ss, red);
+    const float rrms = 1.0f / sqrtf(total / (float)a.n + a.post_eps);
+#pragma unroll
+    for (int j = 0; j < kPostChunks; ++j) {
+        const int c = threadIdx.x + j * 256;
+        if (c < nvec) {
+            const uint4 wv = ld16(a.post_ln_w + c * 8);
+            const uint32_t s4[4] = {keep[j].x, keep[j].y, keep[j].z, keep[j].w};
+            const uint32_t w4[4] = {wv.x, wv.y, wv.z, wv.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = pack_bf16x2((bf16_lo(s4[e]) * rrms) * bf16_lo(w4[e]),
+                                   (bf16_hi(s4[e]) * rrms) * bf16_hi(w4[e]));
+            st16(a.post_out + (int64_t)m * a.ld_post + c * 8, make_uint4(o[0], o[1], o[2], o[3]));
         }
     }
 }
@@ -673,7 +753,8 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
                       int var_from_rounded, const void* w_tiles, const void* bias,
                       const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,
                       int k, void* workspace, size_t workspace_bytes, int flags,
-                      mv_stream_t stream) {
+                      mv_stream_t stream, const void* post_ln_w = nullptr, float post_eps = 0.f,
+                      void* post_out = nullptr, int64_t ld_post = 0, int post_var_from_rounded = 0) {
     if (!x || !w_tiles || !y || m <= 0 || n <= 0 || k <= 0) return MV_ERR_INVALID_ARG;
     if (m > 64 || (n % 16) != 0 || (k % 32) != 0) return MV_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(w_tiles) || (ldx % 8) != 0 || ldx < k) return MV_ERR_INVALID_ARG;
@@ -718,7 +799,24 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     a.ld_sum_out = ld_sum_out;
     a.ksplit = pick_ksplit(m, a.nt, a.kt);
     a.partial = nullptr;
-    if (a.ksplit > 1) {
+    a.post_ln_w = (const uint16_t*)post_ln_w;
+    a.post_out = (uint16_t*)post_out;
+    a.ld_post = ld_post;
+    a.post_eps = post_eps;
+    a.post_var_from_rounded = post_var_from_rounded;
+    if (post_ln_w) {
+        // the norm lives in the slab reduction, so the product always goes through slabs (one
+        // slab when the planner would not split)
+        if (sw || of32 || (n % 8) != 0 || n > 8 * 256 * kPostChunks) return MV_ERR_UNSUPPORTED;
+        if (!post_out || !aligned16(post_ln_w) || !aligned16(post_out) || !aligned16(y) ||
+            (ld_post % 8) != 0 || ld_post < n || (ldy % 8) != 0)
+            return MV_ERR_INVALID_ARG;
+        if ((bias && !aligned16(bias)) || (residual && (!aligned16(residual) || (ld_res % 8) != 0)))
+            return MV_ERR_INVALID_ARG;
+        const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
+        if (!workspace || workspace_bytes < need || !aligned16(workspace)) return MV_ERR_WORKSPACE;
+        a.partial = (float*)workspace;
+    } else if (a.ksplit > 1) {
         const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
         if (!workspace || workspace_bytes < need || !aligned16(workspace)) {
             a.ksplit = 1;  // no room for slabs: fall back to whole strips (slower, same result class)
@@ -765,7 +863,10 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
         }
     }
     if (rc != MV_OK) return rc;
-    if (a.ksplit > 1) {
+    if (post_ln_w) {
+        hipLaunchKernelGGL(wgemm_finalize_norm_kernel, dim3(m), dim3(256), 0, s, a);
+        rc = check_launch();
+    } else if (a.ksplit > 1) {
         const int64_t total = (int64_t)m * ncols;
         int blocks = (int)((total + 255) / 256);
         if (blocks > cus * 4) blocks = cus * 4;
@@ -820,6 +921,23 @@ int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
     return mv::wgemm_impl(x, ldx, nullptr, 0, nullptr, 0.f, nullptr, 0, mv::kProNone, 0, w_tiles, bias,
                           residual, ld_res, y, ldy, m, n, k, workspace, workspace_bytes, flags,
                           stream);
+}
+
+size_t mv_wgemm_postnorm_workspace_bytes(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
+    const int ks = mv::pick_ksplit(m, n / 16, k / 32);
+    return (size_t)(ks > 1 ? ks : 1) * (size_t)m * (size_t)n * sizeof(float);
+}
+
+int mv_wgemm_postnorm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
+                      const void* residual, int64_t ld_res, void* y, int64_t ldy, const void* ln_w,
+                      float eps, void* normed, int64_t ld_normed, int norm_flags, int m, int n, int k,
+                      void* workspace, size_t workspace_bytes, mv_stream_t stream) {
+    if (!ln_w || !normed) return MV_ERR_INVALID_ARG;
+    return mv::wgemm_impl(x, ldx, nullptr, 0, nullptr, 0.f, nullptr, 0, mv::kProNone, 0, w_tiles, bias,
+                          residual, ld_res, y, ldy, m, n, k, workspace, workspace_bytes, 0, stream,
+                          ln_w, eps, normed, ld_normed,
+                          (norm_flags & MV_NORM_VAR_FROM_ROUNDED) ? 1 : 0);
 }
 
 int mv_wgemm_norm(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_r,

@@ -113,6 +113,43 @@ def wgemm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
     return out
 
 
+def wgemm_postnorm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor, ln_weight: torch.Tensor,
+                   eps: float, normed: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                   residual: Optional[torch.Tensor] = None, var_from_rounded: bool = False,
+                   workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x @ W^T (+ bias) (+ residual) as `wgemm`, and normed = rmsnorm(out) * ln_weight in the
+    same pair of launches (the norm rides on the slab reduction).  Without `var_from_rounded` the
+    variance is taken from the unrounded bf16(x @ W^T + bias) + residual: bit-identical to
+    `wgemm` (no residual) followed by `rmsnorm_residual_gemm`; with it, from `out` as stored:
+    bit-identical to `wgemm(..., residual=)` followed by `rmsnorm_`."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    m, k = x.shape
+    assert k == w.k and not w.swiglu
+    n = w.n
+    assert out.shape == (m, n) and out.dtype == torch.bfloat16 and out.stride(1) == 1
+    assert normed.shape == (m, n) and normed.dtype == torch.bfloat16 and normed.stride(1) == 1
+    assert ln_weight.dtype == torch.bfloat16 and ln_weight.numel() == n and ln_weight.is_contiguous()
+    if bias is not None:
+        assert bias.dtype == torch.bfloat16 and bias.numel() == n and bias.is_contiguous()
+    ld_res = 0
+    if residual is not None:
+        assert residual.dtype == torch.bfloat16 and residual.shape == (m, n) and residual.stride(1) == 1
+        ld_res = residual.stride(0) if m > 1 else n
+    L = nv.lib()
+    need = L.mv_wgemm_postnorm_workspace_bytes(m, n, k)
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = gemm_workspace(x.device, need)
+    ldx = x.stride(0) if m > 1 else max(k, x.stride(0))
+    ldy = out.stride(0) if m > 1 else max(n, out.stride(0))
+    ldn = normed.stride(0) if m > 1 else max(n, normed.stride(0))
+    nv.check("mv_wgemm_postnorm", L.mv_wgemm_postnorm(
+        x.data_ptr(), ldx, w.tiles.data_ptr(), nv.ptr(bias), nv.ptr(residual), ld_res,
+        out.data_ptr(), ldy, ln_weight.data_ptr(), eps, normed.data_ptr(), ldn,
+        nv.MV_NORM_VAR_FROM_ROUNDED if var_from_rounded else 0, m, n, k,
+        workspace.data_ptr(), workspace.numel() * workspace.element_size(), nv.stream_ptr()))
+    return out
+
+
 def gemm_prefill(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
                  bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                  swiglu: bool = False) -> torch.Tensor:

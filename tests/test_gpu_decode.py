@@ -189,3 +189,32 @@ def test_duplicate_padded_batch(mv):
     got, want = step_both(cfg, runner, mgr, ref, ref_cache, [0, 1, 2, 0], [11, 21, 31, 11], ids, True)
     assert_close_bf16(got, want, atol=FREE_RUN_ATOL(want), rtol=2 ** -7)
     assert torch.equal(got[0], got[3])
+
+
+@pytest.mark.parametrize("bs", [5, 8])
+def test_batched_path_with_norms_on_the_slab_reduction_equals_the_per_kernel_path(mv, bs):
+    """bs > 4: the decode step whose O and down projections carry the following norm
+    (`_decode_batched`) against the same step built from `_layer` + `_head` (separate norm
+    kernels): same logits, bit for bit, and the same KV written."""
+    from micro_vllm_amd.kernel.linear import embedding
+
+    cfg, r1, m1, _, rc1 = build(mv, "tiny-gqa", n_blocks=40)
+    _, r2, m2, _, rc2 = build(mv, "tiny-gqa", n_blocks=40)
+    seq_lens = [3, 250, 257, 31, 64, 500, 9, 129][:bs]
+    prefill_random_kv(m1, rc1, seq_lens, seed=7)
+    prefill_random_kv(m2, rc2, seq_lens, seed=7)
+    ids = torch.randint(0, cfg.vocab_size, (bs,), generator=torch.Generator().manual_seed(1))
+    for m, r in ((m1, r1), (m2, r2)):
+        for sid in range(bs):
+            m.append(sid)
+        m.cache_batch_data(list(range(bs)), [L + 1 for L in seq_lens])
+        r._input_ids[:bs] = ids.to(DEV)
+    assert r1.fused and r1.world_size == 1
+    a = r1.decode(r1._input_ids[:bs], bs, m1).clone()
+    h = embedding(r2.model.transformer.wte.weight, r2._input_ids[:bs], r2._hidden0[:bs])
+    for layer_idx in range(r2.num_layers):
+        h = r2._layer(h, layer_idx, bs, m2)
+    b = r2._head(h, bs).clone()
+    assert torch.equal(a, b)
+    for li in range(r1.num_layers):
+        assert torch.equal(m1.k_caches[li], m2.k_caches[li]) and torch.equal(m1.v_caches[li], m2.v_caches[li])

@@ -195,3 +195,44 @@ def test_wgemm_norm_prologue_is_bit_identical_to_two_kernels(mv, m, n, k, swiglu
     one = wgemm_norm(x, lw, eps, sw, out(), add_r=r, sum_out=s3, var_from_rounded=True, bias=bias,
                      swiglu=swiglu)
     assert torch.equal(s3, h) and torch.equal(one, two)
+
+
+@pytest.mark.parametrize("m", [1, 4, 5, 16, 32, 33, 64])
+@pytest.mark.parametrize("n,k", [(4096, 4096), (4096, 14336), (512, 1024), (8192, 512)])
+def test_wgemm_postnorm_is_bit_identical_to_separate_kernels(mv, m, n, k):
+    """Projection followed by add+RMSNorm (variance from the unrounded sum) or by residual add and
+    the next block's RMSNorm (variance from the stored sum) against the form where the norm rides
+    on the slab reduction: same bits in the projection output and in the normalised row."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm, wgemm_postnorm
+    from micro_vllm_amd.kernel.rmsnorm_add import rmsnorm_
+    from micro_vllm_amd.kernel.rmsnorm_residual import rmsnorm_residual_gemm
+
+    g = torch.Generator().manual_seed(m * 131 + n + k)
+    x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(DEV)
+    r = torch.randn(m, n, generator=g).to(torch.bfloat16).to(DEV)
+    lw = (1 + 0.2 * torch.randn(n, generator=g)).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16).to(DEV)
+    sw = StreamedWeight.from_linear((torch.randn(n, k, generator=g) * 0.03).to(torch.bfloat16).to(DEV))
+    eps = 1e-5
+    new = lambda: torch.empty(m, n, dtype=torch.bfloat16, device=DEV)
+
+    # matmul -> rmsnorm_residual_gemm(y, r): sum = bf16(y + r), variance from the unrounded y + r
+    for b in (None, bias):
+        y = wgemm(x, sw, new(), bias=b)
+        n2, s2 = new(), new()
+        rmsnorm_residual_gemm(y, r, lw, n2, s2, eps)
+        s1, n1 = new(), new()
+        wgemm_postnorm(x, sw, s1, lw, eps, n1, bias=b, residual=r)
+        assert torch.equal(s1, s2) and torch.equal(n1, n2), f"add+norm m={m} bias={b is not None}"
+    # matmul with residual epilogue -> rmsnorm_ of the stored hidden state
+    h2 = wgemm(x, sw, new(), residual=r)
+    n2 = rmsnorm_(h2, lw, new(), eps)
+    h1, n1 = new(), new()
+    wgemm_postnorm(x, sw, h1, lw, eps, n1, residual=r, var_from_rounded=True)
+    assert torch.equal(h1, h2) and torch.equal(n1, n2), f"residual then norm m={m}"
+    # no residual at all: norm of the projection
+    y2 = wgemm(x, sw, new())
+    n2 = rmsnorm_(y2, lw, new(), eps)
+    y1, n1 = new(), new()
+    wgemm_postnorm(x, sw, y1, lw, eps, n1)
+    assert torch.equal(y1, y2) and torch.equal(n1, n2), f"norm of projection m={m}"
