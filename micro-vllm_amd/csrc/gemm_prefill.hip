@@ -68,6 +68,13 @@ static __device__ unsigned long long g_stamp[4 * 512];
 #else
 #define MV_STAMP(slot) do {} while (0)
 #endif
+// MV_EXP_NO_MFMA (timing experiment, wrong results): operands are delivered and consumed by an empty
+// asm statement instead of the matrix instruction; MV_EXP_NO_BARRIER drops the per-stage barrier.
+#ifdef MV_EXP_NO_MFMA
+#define MV_MFMA(c, a_, b_) asm volatile("" : "+v"(c) : "v"(a_), "v"(b_))
+#else
+#define MV_MFMA(c, a_, b_) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c, 0, 0, 0)
+#endif
 
 __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[3][kPStage];
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
         for (int t = 0; t < kPMT / 2; ++t)
 #pragma unroll
             for (int i = 0; i < kPNT; ++i)
-                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xc[t], acc[i][t], 0, 0, 0);
+                MV_MFMA(acc[i][t], wf[i], xc[t]);
         // The x requests are invisible to the compiler's request counting, so they go out behind
         // the waits for this k-tile's weights: in front of them they would make those waits cover
         // the previous refill as well.
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
         for (int t = kPMT / 2; t < kPMT; ++t)
 #pragma unroll
             for (int i = 0; i < kPNT; ++i)
-                acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xc[t], acc[i][t], 0, 0, 0);
+                MV_MFMA(acc[i][t], wf[i], xc[t]);
     };
     // One stage: request stage s+2 of x (its buffer was last read in stage s-1), two k-tiles, wait
     // for this wave's part of stage s+2 (two weight refills were requested after it), barrier: the
@@ -205,7 +212,9 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
         MV_STAMP(1);
         wait_vmcnt<kPNT>();   // only the second k-tile's refill was requested after the x stage
         MV_STAMP(2);
+#ifndef MV_EXP_NO_BARRIER
         __syncthreads();
+#endif
         MV_STAMP(3);
     };
     // three stages per pass and no branch inside the pass (a branch between stages makes the
