@@ -684,7 +684,7 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint) {
         const int cap = ctx_hint / chunk_rows > 1 ? ctx_hint / chunk_rows : 1;
         if (ns > cap) ns = cap;
     }
-    if (ns > 64) ns = 64;
+    if (ns > 32) ns = 32;  // 64 never beat 32 (one kv head at ctx 4096: 9.5 vs 9.2 us; ctx 16384: equal)
     if (ns < 1) ns = 1;
     return ns;
 }
