@@ -678,6 +678,10 @@ static int pick_ksplit(int m, int nt, int kt) {
     // 20.8 vs 23.7): the second launch that adds the slabs costs more than the imbalance of
     // 1.5 strips per CU.  Splitting only pays when there are far fewer strips than CUs.
     const int cus = num_cus();
+    // ... and for the dot form not even then: shards of tensor-parallel runs (tools/sweep_small_gemv.py,
+    // M=1) run 5.4 us unsplit against 6.5-8.7 us split at 48 strips (N=768, K=4096), 5.8 against
+    // 7.2-10.0 at 96 strips.
+    if (m <= 4 && nt >= 32) return 1;
     int best = 1;
     for (int ks = 2; ks <= kMaxKsplit; ks *= 2) {
         if (kt % ks) break;
@@ -835,7 +839,10 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     // with at most one strip per CU a single 16-wave workgroup hides HBM latency best
     // (O 8.0 -> 7.4 us, down 20.6 -> 20.4); with more strips than CUs two 8-wave workgroups
     // per CU even out the tail (QKV 12.8 -> 11.3 us, gate/up 39.1 -> 37.6).
-    int waves = g_tune_waves ? g_tune_waves : (a.nunits <= cus ? 16 : 8);
+    // Sixteen waves only pay when nearly every CU has a strip and the strip is long: shards with
+    // short k (K=1792: 4.8 vs 5.8 us) or few strips (48: 5.4 vs 5.8) are faster with eight.
+    const bool one_long_strip_per_cu = a.nunits <= cus && a.nunits * 8 >= cus * 7 && a.kt >= 128;
+    int waves = g_tune_waves ? g_tune_waves : (one_long_strip_per_cu ? 16 : 8);
     int bpc = g_tune_bpc ? g_tune_bpc : (m <= 4 && waves == 8 ? 2 : 1);
     if (m <= 4) {
         // LDS limits co-residency; never size the grid past what fits
