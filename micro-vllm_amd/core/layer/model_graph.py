@@ -310,7 +310,7 @@ class ModelGraphRunner:
             for layer_idx in range(self.num_layers):
                 h, pend = self._layer_norm_fused(h, pend, layer_idx, bs, cache_manager)
             logits = self._head(h, bs, pend=pend)
-        elif self.fused and self.world_size == 1:
+        elif self.fused and self.world_size == 1 and self.hidden_dim <= 8192:  # mv_wgemm_postnorm's row limit
             logits = self._decode_batched(h, bs, cache_manager)
         else:
             for layer_idx in range(self.num_layers):
