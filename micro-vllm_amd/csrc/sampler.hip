@@ -157,6 +157,7 @@ static bool am_scratch(AmScratch& sc) {
 // ---------------------------------------------------------------- top-k / top-p sampling
 constexpr int kSmThreads = 1024;
 constexpr int kSmMaxK = 1024;
+constexpr int kSmKeep = 16;   // 16-byte chunks of the row a thread keeps in registers
 
 // order-preserving 16-bit key of a bf16 value (larger key = larger value); NaN sorts lowest
 __device__ __forceinline__ unsigned bf16_key(unsigned bits) {
@@ -192,7 +193,11 @@ __global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __re
                                                           const float* __restrict__ top_ps, int top_k,
                                                           const float* __restrict__ uniforms,
                                                           int64_t* __restrict__ ids) {
-    __shared__ unsigned hist[256];
+    // Sixteen copies of the 256-bin histogram, one per lane group: logits share a handful of
+    // exponents, so with a single copy nearly every lane of a wave adds to the same LDS word and the
+    // adds are served one after the other.  A thread also counts runs of equal bins in a register
+    // and adds a whole run at once.
+    __shared__ unsigned hist[16][256];
     __shared__ unsigned sh_u[8];
     __shared__ float c_val[kSmMaxK];
     __shared__ int c_idx[kSmMaxK];
@@ -204,30 +209,56 @@ __global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __re
     const int nvec = n >> 3;
     const int k = min(min(top_k, n), kSmMaxK);
 
-    auto for_each = [&](auto&& fn) {  // fn(key, index) over the row, 16-byte loads
-        for (int c = tid; c < nvec; c += kSmThreads) {
-            const uint4 v = ld16(row + c * 8);
+    // The row is read ONCE: the first kSmKeep chunks of every thread (rows up to 131 072 entries
+    // whole) stay in registers for all three passes, requested back to back so that the read costs
+    // one memory round trip instead of one per chunk and pass; longer rows stream the rest.
+    uint4 keep[kSmKeep];
+#pragma unroll
+    for (int i = 0; i < kSmKeep; ++i) {
+        const int c = tid + i * kSmThreads;
+        keep[i] = ld16(row + (int64_t)min(c, nvec - 1) * 8);
+    }
+    auto for_each_chunk = [&](auto&& fn) {  // fn(chunk index, 8 values), every thread the same trip count
+#pragma unroll
+        for (int i = 0; i < kSmKeep; ++i) fn(tid + i * kSmThreads, keep[i]);
+        for (int c0 = kSmKeep * kSmThreads; c0 < nvec; c0 += kSmThreads) {
+            const int c = c0 + tid;
+            fn(c, ld16(row + (int64_t)min(c, nvec - 1) * 8));
+        }
+    };
+    auto for_each = [&](auto&& fn) {  // fn(key, index) over the row
+        for_each_chunk([&](int c, const uint4& v) {
+            if (c >= nvec) return;
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 fn(bf16_key(w[j] & 0xffffu), c * 8 + 2 * j);
                 fn(bf16_key(w[j] >> 16), c * 8 + 2 * j + 1);
             }
-        }
+        });
     };
     // the bin (scanning from the top) in which the running count reaches `want`
     auto pick_bin = [&](unsigned want, unsigned& bin, unsigned& above) {
         __syncthreads();
-        if (tid == 0) {
-            unsigned acc = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (acc + hist[b] >= want) break;
-                acc += hist[b];
-            }
-            sh_u[0] = (unsigned)b;
-            sh_u[1] = acc;
+        if (tid < 256) {
+            unsigned t = 0;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) t += hist[c][tid];
+            hist[0][tid] = t;
         }
+        __syncthreads();
+        // suffix sums from bin 255 down, all bins at once: thread t holds bin 255 - t; the first
+        // thread whose running count reaches `want` names the bin (bin 0 if none does)
+        const unsigned h = tid < 256 ? hist[0][255 - tid] : 0u;
+        unsigned total;
+        const unsigned incl = block_scan_incl(h, ws_u, total);
+        if (tid == 0) sh_u[0] = 255u;
+        __syncthreads();
+        if (tid < 255 && incl >= want) atomicMin(&sh_u[0], (unsigned)tid);
+        __syncthreads();
+        if ((unsigned)tid == sh_u[0]) sh_u[1] = incl - h;
+        __syncthreads();
+        if (tid == 0) sh_u[0] = 255u - sh_u[0];
         __syncthreads();
         bin = sh_u[0];
         above = sh_u[1];
@@ -235,16 +266,32 @@ __global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __re
     };
 
     // ---- radix select of the k-th largest key: high byte, then low byte
-    if (tid < 256) hist[tid] = 0;
+    unsigned* my_hist = hist[tid & 15];
+    unsigned run_bin = 0, run_len = 0;
+    auto count = [&](unsigned bin) {
+        if (bin != run_bin) {
+            if (run_len) atomicAdd(&my_hist[run_bin], run_len);
+            run_bin = bin;
+            run_len = 0;
+        }
+        ++run_len;
+    };
+    auto flush = [&]() {
+        if (run_len) atomicAdd(&my_hist[run_bin], run_len);
+        run_len = 0;
+    };
+    for (int i = tid; i < 16 * 256; i += kSmThreads) (&hist[0][0])[i] = 0;
     __syncthreads();
-    for_each([&](unsigned key, int) { atomicAdd(&hist[key >> 8], 1u); });
+    for_each([&](unsigned key, int) { count(key >> 8); });
+    flush();
     unsigned b1, above1;
     pick_bin((unsigned)k, b1, above1);
-    if (tid < 256) hist[tid] = 0;
+    for (int i = tid; i < 16 * 256; i += kSmThreads) (&hist[0][0])[i] = 0;
     __syncthreads();
     for_each([&](unsigned key, int) {
-        if ((key >> 8) == b1) atomicAdd(&hist[key & 255u], 1u);
+        if ((key >> 8) == b1) count(key & 255u);
     });
+    flush();
     unsigned b2, above2;
     pick_bin((unsigned)k - above1, b2, above2);
     const unsigned thr = (b1 << 8) | b2;
@@ -255,14 +302,12 @@ __global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __re
     if (tid == 0) sh_u[2] = 0;
     __syncthreads();
     unsigned eq_base = 0;
-    const int nchunk = (nvec + kSmThreads - 1) / kSmThreads;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int c = ch * kSmThreads + tid;
+    for_each_chunk([&](int c, const uint4& v) {
+        if (c - tid >= nvec) return;  // uniform: this pass of the workgroup lies past the row
         unsigned keys[8];
         unsigned my_eq = 0;
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         if (c < nvec) {
-            const uint4 v = ld16(row + c * 8);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 keys[2 * j] = bf16_key(w[j] & 0xffffu);
@@ -284,8 +329,6 @@ __global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __re
             const unsigned incl = block_scan_incl(my_eq, ws_u, total);
             unsigned rank = eq_base + incl - my_eq;
             if (c < nvec && my_eq) {
-                const uint4 v = ld16(row + c * 8);
-                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (keys[j] == thr) {
@@ -300,7 +343,7 @@ __global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __re
             }
             eq_base += total;
         }
-    }
+    });
     // pad to a power of two for the sort
     int p2 = 1;
     while (p2 < k) p2 <<= 1;
