@@ -1,0 +1,125 @@
+"""The headline configuration's own dimensions (Llama-3-8B: hidden 4096, 32/8 heads of 128, FFN 14336,
+vocab 128 256; two blocks instead of 32 so that the CPU restatement finishes in seconds), context
+4096 through a shuffled block table: decode logits against the oracle, the captured step against
+the eager one, and the fused step against the step built from separate kernels (bit for bit)."""
+import dataclasses
+import random
+
+import pytest
+import torch
+
+from conftest import assert_close_bf16
+from oracle.ref_cache import RefKVCache
+from oracle.ref_model import RefRunner
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CTX = 4096
+
+
+def _build(bs, fused=True, seed=5):
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+    from micro_vllm_amd.core.layer.model_graph import ModelGraphRunner
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = dataclasses.replace(SHAPES["llama3-8b"], num_hidden_layers=2)
+    cpu_model = build_synthetic_model(cfg, "cpu", seed=1234, norm_jitter=0.1)
+    gpu_model = build_synthetic_model(cfg, "cpu", seed=1234, norm_jitter=0.1).to(DEV)
+    n_blocks, max_tokens = bs * (CTX // 256 + 2) + 2, CTX + 512
+    runner = ModelGraphRunner(gpu_model, 2, cfg.num_attention_heads, cfg.head_dim, cfg.num_key_value_heads,
+                              cfg.hidden_size, cfg.intermediate_size, DEV, max_batch_size=bs,
+                              max_blocks=max_tokens // 256, fused=fused)
+    mgr = KVCacheManager(n_blocks, 256, 2, cfg.num_key_value_heads, cfg.head_dim, dtype=torch.bfloat16,
+                         device=DEV, max_tokens=max_tokens, max_batch_size=bs)
+    ref_cache = RefKVCache(n_blocks, 256, 2, cfg.num_key_value_heads, cfg.head_dim, max_tokens=max_tokens,
+                           max_batch_size=bs, strict_reference=False)
+    order = list(mgr._free)
+    random.Random(seed).shuffle(order)           # non-contiguous pages, the same on both sides
+    for pool in (mgr._free, ref_cache.free_blocks):
+        pool.clear()
+        pool.extend(order)
+    g = torch.Generator().manual_seed(seed)
+    lens = [CTX - 3 * i for i in range(bs)]
+    for sid, L in enumerate(lens):
+        ok, slots = mgr.alloc(sid, L)
+        ok2, slots2 = ref_cache.alloc(sid, L)
+        assert ok and ok2 and slots.tolist() == slots2
+    for li in range(2):                          # every slot random: used ones matter, the rest must not
+        k = torch.randn(ref_cache.k_caches[li].shape, generator=g).to(torch.bfloat16)
+        v = torch.randn(ref_cache.v_caches[li].shape, generator=g).to(torch.bfloat16)
+        ref_cache.k_caches[li].copy_(k)
+        ref_cache.v_caches[li].copy_(v)
+        mgr.k_caches[li].copy_(k)
+        mgr.v_caches[li].copy_(v)
+    return cfg, runner, mgr, RefRunner(cpu_model, cfg.head_dim, world=1, max_blocks=max_tokens // 256), ref_cache, lens
+
+
+@pytest.mark.parametrize("bs", [1, 8])
+def test_llama3_8b_dimensions_decode_step(mv, bs):
+    cfg, runner, mgr, ref, ref_cache, lens = _build(bs)
+    sids = list(range(bs))
+    ids = torch.randint(0, cfg.vocab_size, (bs,), generator=torch.Generator().manual_seed(bs))
+    for sid in sids:
+        mgr.append(sid)
+        ref_cache.append(sid)
+    pos = [L + 1 for L in lens]
+    bt, sl = mgr.cache_batch_data(sids, pos)
+    rbt, rsl = ref_cache.cache_batch_data(sids, pos)
+    assert torch.equal(bt.cpu(), rbt) and torch.equal(sl.cpu(), rsl)            # indexing: bit exact
+    runner._input_ids[:bs] = ids.to(DEV)
+    kv_before = [c.clone() for c in mgr.k_caches]
+    eager = runner.decode(runner._input_ids[:bs], bs, mgr).float().cpu()
+    want = ref.decode(ids, [(ref_cache.k_caches, ref_cache.v_caches)], rsl, rbt).float()
+    # Elementwise: the path's 1e-3 plus one bf16 unit at the largest logit (logits of this shape are
+    # O(1), one unit in the last place is 2^-7).  On average: free-running logits of two CORRECT
+    # implementations differ by rounding flips that every further bf16 rounding point amplifies,
+    # so the yardstick is the oracle against itself with one legitimate choice changed (P rounded
+    # to bf16 before P.V, as a matrix-core kernel does); the device path must stay within a small
+    # multiple of that distance, and may only pick another token where the top two logits tie.
+    assert_close_bf16(eager, want, atol=1e-3 + 2.0 ** -7 * float(want.abs().max()), rtol=2 ** -7,
+                      what=f"8B dims bs={bs}")
+    alt = RefRunner(ref.model, cfg.head_dim, world=1, max_blocks=ref_cache.max_seq_blocks, p_bf16=True)
+    alt_l = alt.decode(ids, [(ref_cache.k_caches, ref_cache.v_caches)], rsl, rbt).float()
+    floor = (alt_l - want).abs().mean().item()
+    budget = 4 * floor + 1e-3
+    assert (eager - want).abs().mean().item() <= budget, (floor, (eager - want).abs().mean().item())
+    for b in range(bs):
+        top2 = want[b].topk(2).values
+        if float(top2[0] - top2[1]) > 6 * budget:
+            assert int(eager[b].argmax()) == int(want[b].argmax())
+    # KV: every slot but the appended one is untouched (bit exact); the appended rows come out of
+    # this step's own projections (free running), so they are compared like the logits
+    for li in range(2):
+        for got_c, want_c in ((mgr.k_caches[li].cpu(), ref_cache.k_caches[li]),
+                              (mgr.v_caches[li].cpu(), ref_cache.v_caches[li])):
+            diff = (got_c != want_c).flatten(2).any(-1)          # [block, slot]
+            assert int(diff.sum()) <= bs, "only the appended slots may differ at all"
+            for blk, slot in diff.nonzero().tolist():
+                hit = [(int(rbt[b, p // 256]), p % 256) for b, p in enumerate(pos)]   # the new key lands at cache_seqlens
+                assert (blk, slot) in hit, (blk, slot, hit)
+            assert_close_bf16(got_c.float(), want_c.float(), atol=1e-3 + 2.0 ** -6 * float(want_c.float().abs().max()),
+                              rtol=2 ** -6, what=f"appended KV layer {li}")
+    # captured step == eager step, bit for bit (the append rewrites the same slot with the same bits)
+    runner.capture(mgr, batch_sizes=[bs])
+    assert bs in runner._graphs
+    replay = runner.forward(ids.to(DEV), mgr, bs).float().cpu()
+    assert torch.equal(replay, eager)
+    first_max = torch.stack([(row == row.max()).nonzero()[0, 0] for row in eager])   # lowest index on ties
+    assert torch.equal(runner.greedy_ids(runner._logits[:bs]).cpu(), first_max)
+    del kv_before
+
+
+def test_llama3_8b_dimensions_fused_equals_separate_kernels(mv):
+    """Norm-in-prologue / epilogue-fused step against the step made of the reference's separate ops."""
+    outs = []
+    for fused in (True, False):
+        cfg, runner, mgr, _, _, lens = _build(2, fused=fused)
+        ids = torch.tensor([17, cfg.vocab_size - 2])
+        for sid in range(2):
+            mgr.append(sid)
+        mgr.cache_batch_data([0, 1], [L + 1 for L in lens])
+        runner._input_ids[:2] = ids.to(DEV)
+        outs.append(runner.decode(runner._input_ids[:2], 2, mgr).clone().cpu())
+        del runner, mgr
+        torch.cuda.empty_cache()
+    assert torch.equal(outs[0], outs[1])
