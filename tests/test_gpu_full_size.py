@@ -123,3 +123,73 @@ def test_llama3_8b_dimensions_fused_equals_separate_kernels(mv):
         del runner, mgr
         torch.cuda.empty_cache()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_llama3_8b_dimensions_prefill(mv):
+    """Prefill of 600 tokens (two pages and a part of a third) at the same dimensions: each block
+    teacher-forced on the oracle's input, K/V pages, and the last position's logits free running."""
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+    from micro_vllm_amd.core.layer.model_prefill import ModelPrefillRunner
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    torch.set_num_threads(16)
+    cfg = dataclasses.replace(SHAPES["llama3-8b"], num_hidden_layers=2)
+    cpu_model = build_synthetic_model(cfg, "cpu", seed=1234, norm_jitter=0.1)
+    gpu_model = build_synthetic_model(cfg, "cpu", seed=1234, norm_jitter=0.1).to(DEV)
+    prefill = ModelPrefillRunner(gpu_model, 2, cfg.num_attention_heads, cfg.head_dim, cfg.num_key_value_heads,
+                                 cfg.hidden_size, cfg.intermediate_size, DEV, max_batch_size=1)
+    mgr = KVCacheManager(6, 256, 2, cfg.num_key_value_heads, cfg.head_dim, dtype=torch.bfloat16, device=DEV,
+                         max_tokens=1024, max_batch_size=1)
+    ref_cache = RefKVCache(6, 256, 2, cfg.num_key_value_heads, cfg.head_dim, max_tokens=1024, max_batch_size=1,
+                           strict_reference=False)
+    for pool in (mgr._free, ref_cache.free_blocks):
+        pool.clear()
+        pool.extend([4, 1, 5, 0, 2, 3])
+    # the matrix-core attention rounds P to bf16: compare with the oracle form that does the same
+    ref = RefRunner(cpu_model, cfg.head_dim, world=1, p_bf16=True)
+    S = 600
+    ids = torch.randint(0, cfg.vocab_size, (1, S), generator=torch.Generator().manual_seed(9))
+    assert mgr.alloc(0, S)[0] and ref_cache.alloc(0, S)[0]
+    bt, _ = mgr.cache_batch_data([0], [S])
+    rbt, _ = ref_cache.cache_batch_data([0], [S])
+    assert torch.equal(bt.cpu(), rbt)
+    trace = []
+    want = ref.prefill(ids, [(ref_cache.k_caches, ref_cache.v_caches)], rbt, trace=trace)[:, -1].float()
+
+    alt_cache = RefKVCache(6, 256, 2, cfg.num_key_value_heads, cfg.head_dim, max_tokens=1024, max_batch_size=1,
+                           strict_reference=False)
+    alt_cache.free_blocks.clear()
+    alt_cache.free_blocks.extend([4, 1, 5, 0, 2, 3])
+    alt_cache.alloc(0, S)
+    alt = RefRunner(cpu_model, cfg.head_dim, world=1, p_bf16=False)
+    alt_trace = []
+    alt_l = alt.prefill(ids, [(alt_cache.k_caches, alt_cache.v_caches)], rbt, trace=alt_trace)[:, -1].float()
+    floors = [(alt_trace[li + 1].float() - trace[li + 1].float()).abs().mean().item() for li in range(2)]
+
+    lens = mgr._cache_seqlens_buffer[:1].zero_()
+    for li in range(2):
+        h_in = trace[li].reshape(S, -1).to(DEV)
+        out = prefill._prefill_layer(h_in, li, 1, S, mgr, lens, mgr._block_table_buffer[:1])
+        w = trace[li + 1].reshape(S, -1).float()
+        # bound per element as in the small-model test: the path's 1e-3, one bf16 unit at the row's
+        # largest magnitude and one at the element's own addends; the mean far below
+        err = (out.float().cpu() - w).abs()
+        hin = trace[li].reshape(S, -1).float().abs()
+        tol = 1e-3 + 2 ** -7 * w.abs().amax(dim=-1, keepdim=True) + 2 ** -7 * torch.maximum(w.abs(), hin)
+        assert bool((err <= tol).all()), f"prefill layer {li}: max err {err.max().item():.3e}"
+        # on average: within a small multiple of what the oracle differs from ITSELF on this block
+        # when P is kept in fp32 instead of being rounded to bf16 (hidden states of this width are
+        # O(1..10), an absolute figure would say nothing)
+        assert err.mean().item() <= 4 * floors[li] + 1e-3, \
+            f"prefill layer {li}: mean err {err.mean().item():.3e}, oracle-vs-oracle {floors[li]:.3e}"
+        kmax = float(ref_cache.k_caches[li].float().abs().max())
+        assert_close_bf16(mgr.k_caches[li], ref_cache.k_caches[li], atol=1e-3 + 2 ** -7 * kmax, rtol=2 ** -7)
+        assert_close_bf16(mgr.v_caches[li], ref_cache.v_caches[li], atol=1e-3 + 2 ** -8 * kmax, rtol=2 ** -7)
+
+    got = prefill.forward(ids.to(DEV), mgr, 1, last_token_only=True)[:, -1].float().cpu()
+    floor = (alt_l - want).abs().mean().item()
+    budget = 4 * floor + 1e-3
+    assert (got - want).abs().mean().item() <= budget, (floor, (got - want).abs().mean().item())
+    top2 = want[0].topk(2).values
+    if float(top2[0] - top2[1]) > 6 * budget:
+        assert int(got.argmax()) == int(want.argmax())
