@@ -133,3 +133,61 @@ def test_engine_generate_api_and_sampling_path(mv):
     for text in out.values():
         ids = [int(t) for t in text.split()]
         assert all(0 <= t < cfg.vocab_size for t in ids)
+
+
+def test_engine_soak_many_ragged_requests(mv):
+    """120 requests of ragged prompt lengths (1..700 tokens, crossing zero to two page boundaries),
+    1..24 new tokens each, greedy and sampled mixed, batches of up to 8 with every captured graph
+    size in play: every request finishes with exactly the tokens it asked for (no end-of-sequence
+    id in the vocabulary the stub tokenizer emits), every token is streamed once, no id leaves the
+    vocabulary, and every page is back in the pool at the end - repeatedly, so pages freed by one
+    wave of requests are reused by the next."""
+    import random
+
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.core.inference_context import BatchInferenceContext
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES["tiny-gqa"]
+    tok = Tok(cfg.vocab_size)
+    gpu_model = build_synthetic_model(cfg, "cpu", seed=11, norm_jitter=0.1).to(DEV)
+    n_blocks = 200   # the scheduler admits prefills without looking at the pool (as the reference): room for all
+    eng = InferenceEngine(model=gpu_model, tokenizer=tok, max_batch_size=8, n_blocks=n_blocks, max_tokens=1024,
+                          graph_batch_sizes=[1, 2, 4, 8], prefill_timeout=0.0)
+    eng.eos_token_id = None
+    rnd = random.Random(5)
+    torch.manual_seed(5)
+    for wave in range(3):
+        want_len, streamed = {}, {}
+        for i in range(40):
+            plen = rnd.choice([1, 2, 17, 255, 256, 257, 300, 511, 513, 700])
+            prompt = "".join(chr(33 + rnd.randrange(90)) for _ in range(plen))
+            new = rnd.randint(1, 24)
+            sid = eng.add_request(prompt + f"#{wave}.{i}", max_tokens=new, temperature=rnd.choice([0.0, 0.0, 0.7, 1.3]),
+                                  top_p=rnd.choice([0.5, 0.9, 1.0]))
+            want_len[sid] = new
+            streamed[sid] = []
+            eng.register_stream_callback(sid, lambda t, txt, sid=sid: streamed[sid].append(t))
+        seqs = {s.seq_id: s for s in eng.scheduler.waiting_queue}
+        assert len(seqs) == 40, "request ids collided"
+        sizes = set()
+        for _ in range(20000):
+            batch, kind = eng.get_next_batch()
+            if kind == "waiting":
+                continue
+            if not batch:
+                break
+            sizes.add((kind, len(batch)))
+            ctx = BatchInferenceContext(len(batch), kind, batch)
+            assert eng.step(ctx)
+            eng.update_sequences(ctx.sequences)
+        assert not eng.scheduler.waiting_queue
+        for sid, s in seqs.items():
+            assert s.is_finished()
+            assert len(s.output_ids) == want_len[sid], (len(s.output_ids), want_len[sid])
+            assert streamed[sid] == s.output_ids
+            assert all(0 <= t < cfg.vocab_size for t in s.output_ids)
+        assert eng.cache_manager.stats["free"] == n_blocks
+        assert {n for k, n in sizes if k == "decode"} >= {1, 2, 4, 8} or wave > 0
+        eng.scheduler.get_finished_results()
+        eng.scheduler.running_sequences.clear()
