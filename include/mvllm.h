@@ -152,6 +152,15 @@ int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void*
                     const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,
                     int k, int flags, mv_stream_t stream);
 
+/* The same with a workspace for k-slices: when M x N alone gives fewer output tiles than the chip
+ * has CUs (prompts of up to a few hundred tokens), k is cut into slices that run side by side and
+ * a second launch adds them (fp32, in order) and applies the epilogue.  Without the workspace
+ * (or with too small a one) the call behaves like mv_gemm_prefill. */
+size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k);
+int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
+                       const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,
+                       int k, int flags, void* workspace, size_t workspace_bytes, mv_stream_t stream);
+
 /* ---------------------------------------------------- paged attention */
 
 /* Bytes of fp32 workspace for split-KV partial results. */

@@ -92,5 +92,8 @@ inline int check_launch() {
 }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int num_cus();  // compute units of the current device (cached)
+// wgemm.hip: adds k-slices partial[ks][m][n] (fp32) in order and applies the projection epilogue
+int launch_wgemm_finalize(float* partial, int ksplit, int m, int n, int flags, const uint16_t* bias,
+                          const uint16_t* residual, int64_t ld_res, void* y, int64_t ldy, hipStream_t s);
 
 }  // namespace mv

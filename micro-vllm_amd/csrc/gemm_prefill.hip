@@ -50,6 +50,10 @@ struct PGemmArgs {
     int nt, kt;       // 16-row strips, 32-wide k-tiles
     int mblocks, nblocks, nb_per_xcd;
     int flags;
+    // k-split: slice ks of a tile covers k-tiles [ks * ktps, (ks + 1) * ktps) and writes its fp32
+    // accumulators to partial[ks][m][n]; a second launch adds the slices and applies the epilogue
+    int ksplit, ktps;
+    float* partial;
 };
 
 #ifdef MV_GEMM_STAMP
@@ -85,7 +89,10 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
 
     // blockIdx -> (m-block, n-block): an XCD takes a contiguous range of n-blocks and walks the
     // m-blocks fastest
-    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int tiles = 8 * a.nb_per_xcd * a.mblocks;
+    const int ks = blockIdx.x / tiles, bid = blockIdx.x - ks * tiles;
+    const int kt0 = ks * a.ktps;               // first k-tile of this slice
+    const int xcd = bid & 7, idx = bid >> 3;
     const int nb = xcd * a.nb_per_xcd + idx / a.mblocks;
     const int mb = idx % a.mblocks;
     if (nb >= a.nblocks || idx / a.mblocks >= a.nb_per_xcd) return;
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     const uint4* wp[kPNT];
 #pragma unroll
     for (int i = 0; i < kPNT; ++i)
-        wp[i] = a.w + (int64_t)min(nt0 + i, a.nt - 1) * a.kt * 64 + lane;
+        wp[i] = a.w + ((int64_t)min(nt0 + i, a.nt - 1) * a.kt + kt0) * 64 + lane;
 
     // ---- x: global -> LDS directly, three stages deep, in fragment order ---------------------
     // The LDS image of a stage is 16 fragment tiles (8 m-tiles x 2 k-tiles) of 1 KiB in MFMA
@@ -107,12 +114,12 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     // order and waits for ALL outstanding loads before every weight use and every LDS read;
     // hidden from it they only make its counted waits wait for more (requests complete in
     // order), never for less.  The wait that makes the data usable is placed by hand.
-    const int nstage = a.kt >> 1;  // K is a multiple of 64 (checked on the host)
+    const int nstage = a.ktps >> 1;  // a slice is a multiple of 64 k (checked on the host)
     const uint16_t* xg[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int tile = wid * 4 + j;
-        xg[j] = a.x + (int64_t)min(m0 + (tile >> 1) * 16 + r, a.m - 1) * a.ldx + ((tile & 1) * 4 + q) * 8;
+        xg[j] = a.x + (int64_t)min(m0 + (tile >> 1) * 16 + r, a.m - 1) * a.ldx + kt0 * 32 + ((tile & 1) * 4 + q) * 8;
     }
     const unsigned xs_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)&xs[0][0];
     auto x_fetch = [&](int s, int buf) {
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     // of the k-tile after the one that used it
     uint4 wA[kPNT], wB[kPNT], wC[kPNT];
     auto w_load = [&](uint4(&w)[kPNT], int kt) {
-        const int ktc = min(kt, a.kt - 1);
+        const int ktc = min(kt, a.ktps - 1);
 #pragma unroll
         for (int i = 0; i < kPNT; ++i) {
 #ifdef MV_EXP_NO_WLOAD
@@ -240,7 +247,10 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
         for (int t = 0; t < kPMT; ++t) {
             const int m = m0 + t * 16 + r;
             const f32x4_t c = acc[i][t];
-            if (sw) {
+            if (a.partial) {
+                if (m < a.m)
+                    *reinterpret_cast<f32x4_t*>(&a.partial[((int64_t)ks * a.m + m) * a.n + n0]) = c;
+            } else if (sw) {
                 // rows 0..7 of the tile are up, 8..15 the matching gates: 32 lanes further
                 f32x4_t g;
 #pragma unroll
@@ -283,9 +293,52 @@ extern "C" int mv_debug_read_stamps(void* dst, size_t bytes) {
 }
 #endif
 
+namespace mv {
+// k-slices for an M x N product over kt k-tiles: none when the output tiles alone fill the chip.
+// Otherwise a small cost model picks the count (measured on MI355X: a workgroup walks k at about
+// 1.1 us per 64-k stage when the chip is mostly idle; the slices cost a second launch, about 4 us,
+// plus writing and re-reading ks x M x N floats at about 3 TB/s).  One 256 x 128 tile per
+// workgroup walks k serially: at 128 tokens the QKV projection of the 8B shape has 24 tiles and
+// took 70 us with nine tenths of the chip idle, 36 us split; the gate/up projection at 256 tokens
+// (224 tiles) is faster unsplit because its slices would be 117 MB.
+static int prefill_ksplit(int m, int n, int kt) {
+    const int cus = num_cus();
+    const long tiles = (long)((m + kPM - 1) / kPM) * ((n + kPN - 1) / kPN);
+    if (tiles >= cus) return 1;
+    int best = 1;
+    double best_us = 1e30;
+    for (int ks = 1; ks <= 16; ks *= 2) {
+        if (ks > 1 && (kt % (2 * ks) != 0 || kt / ks < 8)) break;
+        const long rounds = (tiles * ks + 2L * cus - 1) / (2L * cus);
+        double us = (double)rounds * (kt / (2.0 * ks)) * 1.1;
+        if (ks > 1) us += 4.0 + 8.0 * ks * (double)m * n / 3.0e6;
+        if (us < best_us) {
+            best_us = us;
+            best = ks;
+        }
+    }
+    return best;
+}
+}  // namespace mv
+
+extern "C" size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k) {
+    using namespace mv;
+    if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
+    const int ks = prefill_ksplit(m, n, k / 32);
+    return ks > 1 ? (size_t)ks * m * n * sizeof(float) : 0;
+}
+
 extern "C" int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
                                const void* residual, int64_t ld_res, void* y, int64_t ldy, int m,
                                int n, int k, int flags, mv_stream_t stream) {
+    return mv_gemm_prefill_ws(x, ldx, w_tiles, bias, residual, ld_res, y, ldy, m, n, k, flags, nullptr, 0,
+                              stream);
+}
+
+extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
+                                  const void* residual, int64_t ld_res, void* y, int64_t ldy, int m,
+                                  int n, int k, int flags, void* workspace, size_t workspace_bytes,
+                                  mv_stream_t stream) {
     using namespace mv;
     if (m == 0) return MV_OK;
     if (!x || !w_tiles || !y || m < 0 || n <= 0 || k <= 0) return MV_ERR_INVALID_ARG;
@@ -317,8 +370,21 @@ extern "C" int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, 
     a.nblocks = (n + kPN - 1) / kPN;
     a.nb_per_xcd = (a.nblocks + 7) / 8;
     a.flags = flags;
-    const long grid = 8L * a.nb_per_xcd * a.mblocks;
+    a.ksplit = prefill_ksplit(m, n, a.kt);
+    a.partial = nullptr;
+    if (a.ksplit > 1) {
+        const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
+        if (workspace && workspace_bytes >= need && aligned16(workspace))
+            a.partial = (float*)workspace;
+        else
+            a.ksplit = 1;  // no room for the slices: whole k per tile (slower, same result class)
+    }
+    a.ktps = a.kt / a.ksplit;
+    const long grid = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
     if (grid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(gemm_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);
-    return check_launch();
+    int rc = check_launch();
+    if (rc != MV_OK || a.ksplit == 1) return rc;
+    return launch_wgemm_finalize(a.partial, a.ksplit, m, n, flags, a.bias, a.residual, ld_res, y, ldy,
+                                 (hipStream_t)stream);
 }

@@ -657,6 +657,30 @@ __global__ __launch_bounds__(256) void wgemm_finalize_norm_kernel(GemmArgs a) {
     }
 }
 
+// The slab reduction for other kernels of the library that split k (the prefill GEMM): same
+// layout partial[ks][m][n], same epilogues.
+int launch_wgemm_finalize(float* partial, int ksplit, int m, int n, int flags, const uint16_t* bias,
+                          const uint16_t* residual, int64_t ld_res, void* y, int64_t ldy, hipStream_t s) {
+    GemmArgs a = {};
+    a.partial = partial;
+    a.ksplit = ksplit;
+    a.m = m;
+    a.n = n;
+    a.flags = flags;
+    a.bias = bias;
+    a.residual = residual;
+    a.ld_res = ld_res;
+    a.y = y;
+    a.ldy = ldy;
+    const int ncols = (flags & MV_GEMM_SWIGLU) ? n / 2 : n;
+    const int64_t total = (int64_t)m * ncols;
+    int64_t blocks = (total + 255) / 256;
+    const int most = num_cus() * 8;
+    if (blocks > most) blocks = most;
+    hipLaunchKernelGGL(wgemm_finalize_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return check_launch();
+}
+
 // ------------------------------------------------------------ host planning
 // k-slices per strip: balance whole units over the CUs.  Cost in tiles per CU,
 // with a split paying roughly one extra kernel boundary.

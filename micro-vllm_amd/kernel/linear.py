@@ -175,9 +175,13 @@ def gemm_prefill(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
         ld_res = residual.stride(0) if m > 1 else w.n
     ldx = x.stride(0) if m > 1 else max(k, x.stride(0))
     ldy = out.stride(0) if m > 1 else max(ncols, out.stride(0))
-    nv.check("mv_gemm_prefill", nv.lib().mv_gemm_prefill(
+    L = nv.lib()
+    need = L.mv_gemm_prefill_workspace_bytes(m, w.n, k)   # k-slices for short prompts, else 0
+    ws = gemm_workspace(x.device, need)
+    nv.check("mv_gemm_prefill_ws", L.mv_gemm_prefill_ws(
         x.data_ptr(), ldx, w.tiles.data_ptr(), nv.ptr(bias), nv.ptr(residual), ld_res,
-        out.data_ptr(), ldy, m, w.n, k, flags, nv.stream_ptr()))
+        out.data_ptr(), ldy, m, w.n, k, flags, ws.data_ptr() if ws is not None else None,
+        ws.numel() * 4 if ws is not None else 0, nv.stream_ptr()))
     return out
 
 

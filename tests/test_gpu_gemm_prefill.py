@@ -92,3 +92,66 @@ def test_gemm_prefill_rejects_bad_shapes(mv):
     with pytest.raises(AssertionError):  # K = 96 is not a multiple of 64
         gemm_prefill(x, w, torch.empty(4, 64, dtype=torch.bfloat16, device=DEV))
     assert gemm_prefill(x[:0], w, torch.empty(0, 64, dtype=torch.bfloat16, device=DEV)).shape == (0, 64)
+
+
+@pytest.mark.parametrize("m", [1, 32, 100, 128, 300, 512])
+@pytest.mark.parametrize("n,k,mode", [(512, 4096, "plain"), (4096, 14336, "residual"), (1536, 4096, "swiglu"),
+                                      (6144, 4096, "bias"), (256, 8192, "f32")])
+def test_gemm_prefill_k_slices(mv, m, n, k, mode):
+    """Few output tiles and a long k: the product is cut into k-slices that run side by side and are
+    added by a second launch (with the epilogue).  Against the oracle as the unsplit product is,
+    and against the unsplit product itself (the C entry without a workspace): the two differ only
+    in fp32 summation order."""
+    import ctypes
+
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    L = nv.lib()
+    assert L.mv_gemm_prefill_workspace_bytes(m, n, k) > 0, "this shape is meant to be split"
+    x, w, g = _mk(m, n, k, seed=m + n + k, scale=0.03)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16) if mode == "bias" else None
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16) if mode == "residual" else None
+    swiglu = mode == "swiglu"
+    if swiglu:
+        sw = StreamedWeight.from_up_gate(w[:n // 2].to(DEV), w[n // 2:].to(DEV))
+    else:
+        sw = StreamedWeight.from_linear(w.to(DEV))
+    ncols = sw.out_features
+    dt = torch.float32 if mode == "f32" else torch.bfloat16
+    xd = x.to(DEV)
+    split = gemm_prefill(xd, sw, torch.empty(m, ncols, dtype=dt, device=DEV),
+                         bias=None if bias is None else bias.to(DEV),
+                         residual=None if res is None else res.to(DEV), swiglu=swiglu)
+    whole = torch.empty(m, ncols, dtype=dt, device=DEV)
+    flags = (nv.MV_GEMM_SWIGLU if swiglu else 0) | (nv.MV_GEMM_OUT_F32 if mode == "f32" else 0)
+    rd = None if res is None else res.to(DEV)
+    bd = None if bias is None else bias.to(DEV)
+    nv.check("mv_gemm_prefill", L.mv_gemm_prefill(
+        xd.data_ptr(), k, sw.tiles.data_ptr(), nv.ptr(bd), nv.ptr(rd), n if rd is not None else 0,
+        whole.data_ptr(), ncols, m, n, k, flags, nv.stream_ptr()))
+    want32 = x.float() @ w.float().t()
+    scale = max(1.0, want32.abs().max().item())
+    if mode == "f32":
+        assert (split.cpu() - want32).abs().max().item() <= 1e-4 * scale
+        assert (split - whole).abs().max().item() <= 1e-4 * scale
+        return
+    if swiglu:
+        want = swiglu_ref(linear_ref(x, w))
+        assert_close_bf16(split, want, atol=1e-3, rtol=2 ** -6, what="k-sliced swiglu")
+        assert_close_bf16(split, whole.cpu(), atol=1e-3, rtol=2 ** -6, what="k-sliced vs whole swiglu")
+    else:
+        # Every rounding point may flip by one unit in the last place AT ITS OWN MAGNITUDE between
+        # two fp32 summation orders, and the flip survives where a later addend cancels most of
+        # the value: the bound is taken at the largest intermediate, not at the result.
+        t0 = linear_ref(x, w).float()
+        t1 = linear_ref(x, w, bias).float()
+        want = t1 if res is None else (t1 + res.float()).to(torch.bfloat16).float()
+        mag = torch.maximum(torch.maximum(t0.abs(), t1.abs()), want.abs())
+        tol = 1e-3 + 2 ** -6 * mag
+        for other, name in ((want, "oracle"), (whole.cpu().float(), "whole")):
+            err = (split.cpu().float() - other).abs()
+            assert bool((err <= tol).all()), f"{mode} vs {name}: max err {err.max().item():.3e}"
+        want = want.to(torch.bfloat16)
+    assert float((ulp_diff(split, want) == 0).float().mean()) > 0.98
+    assert float((ulp_diff(split, whole) == 0).float().mean()) > 0.98
