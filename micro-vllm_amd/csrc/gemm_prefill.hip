@@ -299,7 +299,7 @@ namespace mv {
 // 1.1 us per 64-k stage when the chip is mostly idle; the slices cost a second launch, about 4 us,
 // plus writing and re-reading ks x M x N floats at about 3 TB/s).  One 256 x 128 tile per
 // workgroup walks k serially: at 128 tokens the QKV projection of the 8B shape has 24 tiles and
-// took 70 us with nine tenths of the chip idle, 36 us split; the gate/up projection at 256 tokens
+// took 70 us with nine tenths of the chip idle, 29 us split; the gate/up projection at 256 tokens
 // (224 tiles) is faster unsplit because its slices would be 117 MB.
 static int prefill_ksplit(int m, int n, int kt) {
     const int cus = num_cus();

@@ -1,4 +1,6 @@
-"""TFLOP/s of mv_gemm_prefill on the prefill projections of the 8B shape."""
+"""TFLOP/s of mv_gemm_prefill on the prefill projections of the 8B shape.  Weights rotate over
+more than 600 MB so that every launch streams them from HBM (a single weight would sit in the
+Infinity Cache and flatter short prompts): python tools/bench_gemm_prefill.py [M ...]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -6,18 +8,24 @@ from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
 dev = "cuda"
 ms = [int(a) for a in sys.argv[1:]] or [512, 2048, 4096]
 for m in ms:
+    tot = 0.0
     for (n, k, sw) in [(6144, 4096, False), (4096, 4096, False), (28672, 4096, True), (4096, 14336, False)]:
-        w = StreamedWeight(torch.empty(n * k, dtype=torch.bfloat16, device=dev).normal_(0, 0.02), n, k, sw)
+        copies = max(4, int(600e6 / (n * k * 2)) + 1)
+        ws = [StreamedWeight(torch.empty(n * k, dtype=torch.bfloat16, device=dev).normal_(0, 0.02), n, k, sw)
+              for _ in range(copies)]
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
         y = torch.empty(m, n // 2 if sw else n, dtype=torch.bfloat16, device=dev)
-        for _ in range(3):
+        for w in ws:
             gemm_prefill(x, w, y, swiglu=sw)
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
+        reps = 3
         e0.record()
         for _ in range(reps):
-            gemm_prefill(x, w, y, swiglu=sw)
+            for w in ws:
+                gemm_prefill(x, w, y, swiglu=sw)
         e1.record(); torch.cuda.synchronize()
-        t = e0.elapsed_time(e1) / reps * 1e-3
+        t = e0.elapsed_time(e1) / (reps * copies) * 1e-3
+        tot += t
         print(f"M={m:5d} N={n:6d} K={k:6d}: {t*1e6:9.1f} us  {2*m*n*k/t/1e12:7.1f} TFLOP/s", flush=True)
+    print(f"M={m:5d} sum {tot*1e6:.1f} us", flush=True)
