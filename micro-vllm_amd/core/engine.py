@@ -84,6 +84,7 @@ class InferenceEngine:
         # overwritten before its copy has run; two rows keep that true if a caller pipelines.
         self._ids_host = [torch.zeros(max_batch_size, dtype=torch.long, pin_memory=True) for _ in range(2)]
         self._ids_slot = 0
+        self._sample_params = (None, None, None)
         self.eos_token_id = getattr(tokenizer, "eos_token_id", None)
         self.stream_callbacks = {}
         self.max_position = getattr(cfg, "max_position_embeddings", 4096)
@@ -208,8 +209,13 @@ class InferenceEngine:
             if ids is not None:
                 next_tokens = ids.tolist()
             else:
-                temps = torch.tensor([seq.temperature for seq in batch], device=device)
-                topp = torch.tensor([seq.top_p for seq in batch], device=device)
+                # the same sequences decode step after step: their sampling parameters go to the
+                # device once per batch composition, not once per step
+                key = tuple((seq.temperature, seq.top_p) for seq in batch)
+                if self._sample_params[0] != key:
+                    self._sample_params = (key, torch.tensor([t for t, _ in key], device=device),
+                                           torch.tensor([p for _, p in key], device=device))
+                _, temps, topp = self._sample_params
                 next_tokens = self._sample(logits, temps, topp, 50)
             for i, seq in enumerate(batch):
                 seq._next_token = next_tokens[i]
