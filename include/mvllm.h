@@ -253,6 +253,13 @@ int mv_sample_topk_topp(const void* logits, int64_t ld, int rows, int n, const f
                         const float* top_ps, int top_k, const float* uniforms, int64_t* ids,
                         mv_stream_t stream);
 
+/* The same, for use inside a captured decode step: rows with temperature <= 0 take
+ * greedy_ids[r] (the caller's mv_argmax result) without looking at the logits, so a step that
+ * always contains this launch costs greedy batches nothing.  greedy_ids == NULL: as above. */
+int mv_sample_or_greedy(const void* logits, int64_t ld, int rows, int n, const float* temperatures,
+                        const float* top_ps, int top_k, const float* uniforms,
+                        const int64_t* greedy_ids, int64_t* ids, mv_stream_t stream);
+
 /* ------------------------------------------------------------ hipGraph */
 
 /* Capture everything launched on `stream` between begin and end into an

@@ -62,6 +62,7 @@ PROTOTYPES = {
     "mv_store_kv": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "mv_argmax": (_I, [_P, _L, _I, _I, _P, _P]),
     "mv_sample_topk_topp": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P]),
+    "mv_sample_or_greedy": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "mv_graph_begin_capture": (_I, [_P]),
     "mv_graph_end_capture": (_I, [_P, ctypes.POINTER(c_void_p)]),
     "mv_graph_launch": (_I, [_P, _P]),

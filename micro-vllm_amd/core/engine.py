@@ -84,7 +84,7 @@ class InferenceEngine:
         # overwritten before its copy has run; two rows keep that true if a caller pipelines.
         self._ids_host = [torch.zeros(max_batch_size, dtype=torch.long, pin_memory=True) for _ in range(2)]
         self._ids_slot = 0
-        self._sample_params = (None, None, None)
+        self._sample_params = None   # (temperature, top_p) per row as last sent to the runner
         self.eos_token_id = getattr(tokenizer, "eos_token_id", None)
         self.stream_callbacks = {}
         self.max_position = getattr(cfg, "max_position_embeddings", 4096)
@@ -203,19 +203,25 @@ class InferenceEngine:
             if first[i] and self.cache_manager.append(seq.seq_id) == -1:
                 raise RuntimeError("OOM")
         self.cache_manager.cache_batch_data([s.seq_id for s in batch], [s.current_position for s in batch])
+        # The pick (argmax, or temperature / top-k / top-p draw) is part of the captured step: the
+        # runner's static per-row parameters are rewritten when the batch composition changes, the
+        # uniform numbers before every step that draws, and the only wait of the step is the
+        # read-back of the ids.  (Launching the sampler behind the graph instead costs 0.3 ms per
+        # step at bs 8: the launch has to wait for the graph's own submission.)
+        key = tuple((max(float(seq.temperature), 0.0), float(seq.top_p)) for seq in batch)
+        if self._sample_params != key:
+            self.graph_runner.set_sampling([t for t, _ in key], [p for _, p in key])
+            self._sample_params = key
+        if not all_greedy:
+            self.graph_runner.draw_uniforms(batch_size)
         logits = self.graph_runner.forward(input_ids, self.cache_manager, batch_size)
         if rank0():
-            ids = self.graph_runner.greedy_ids(logits) if all_greedy else None
+            ids = self.graph_runner.picked_ids(logits)
             if ids is not None:
                 next_tokens = ids.tolist()
-            else:
-                # the same sequences decode step after step: their sampling parameters go to the
-                # device once per batch composition, not once per step
-                key = tuple((seq.temperature, seq.top_p) for seq in batch)
-                if self._sample_params[0] != key:
-                    self._sample_params = (key, torch.tensor([t for t, _ in key], device=device),
-                                           torch.tensor([p for _, p in key], device=device))
-                _, temps, topp = self._sample_params
+            else:   # logits from somewhere else than the runner's static buffer
+                temps = torch.tensor([t for t, _ in key], device=device)
+                topp = torch.tensor([p for _, p in key], device=device)
                 next_tokens = self._sample(logits, temps, topp, 50)
             for i, seq in enumerate(batch):
                 seq._next_token = next_tokens[i]

@@ -27,7 +27,7 @@ from ...kernel.linear import (StreamedWeight, add_, embedding, gemm_workspace, w
 from ...kernel.rmsnorm_add import rmsnorm_
 from ...kernel.rmsnorm_residual import rmsnorm_residual_gemm
 from ...kernel.swiglu import swiglu_gemm
-from .sampler import greedy
+from .sampler import greedy, sample
 
 logger = logging.getLogger(__name__)
 
@@ -164,6 +164,15 @@ class ModelGraphRunner:
         # argmax of every row of the last decode's logits: part of the captured step, so greedy
         # decoding needs no launch of its own after the graph
         self._greedy = torch.zeros(max_b, dtype=torch.long, device=dev)
+        # Stochastic pick inside the captured step as well: per-row temperature / top-p / uniform
+        # number live in static buffers the engine rewrites between steps; rows with temperature 0
+        # (the buffers' initial state) take the greedy id and cost nothing.  `_picked` is what a
+        # caller reads back: greedy or sampled, row by row.
+        self.decode_top_k = 50       # core/engine.py:272 (`self._sample(logits, temps, topp, 50)`)
+        self._samp_temp = torch.zeros(max_b, dtype=torch.float32, device=dev)
+        self._samp_topp = torch.ones(max_b, dtype=torch.float32, device=dev)
+        self._samp_u = torch.zeros(max_b, dtype=torch.float32, device=dev)
+        self._picked = torch.zeros(max_b, dtype=torch.long, device=dev)
         self._hidden0 = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
         self._normed = torch.empty((max_b, self.hidden_dim), dtype=dt, device=dev)
         self._qkv = torch.empty(max_b, qkv_dim, dtype=dt, device=dev)
@@ -317,7 +326,34 @@ class ModelGraphRunner:
                 h = self._layer(h, layer_idx, bs, cache_manager)
             logits = self._head(h, bs)
         greedy(logits, out=self._greedy)
+        if self.vocab_size % 8 == 0:
+            sample(logits, self._samp_temp[:bs], self._samp_topp[:bs], min(self.decode_top_k, self.vocab_size),
+                   uniforms=self._samp_u[:bs], out=self._picked, greedy_ids=self._greedy)
+        else:                         # the device sampler wants rows of a multiple of 8
+            self._picked[:bs].copy_(self._greedy[:bs])
         return logits
+
+    def picked_ids(self, logits: torch.Tensor):
+        """The token of every row of the last decode - drawn with the row's temperature / top-p /
+        uniform number as they stood in the static buffers when the step ran, or the argmax for
+        temperature 0 - if `logits` are what that decode returned, else None."""
+        if logits.data_ptr() == self._logits.data_ptr() and logits.shape[1] == self.vocab_size:
+            return self._picked[:logits.shape[0]]
+        return None
+
+    def set_sampling(self, temperatures, top_ps):
+        """Per-row temperature and top-p for the steps to come (host lists; rows not named keep
+        temperature 0 = greedy).  Call when the batch composition changes."""
+        n = len(temperatures)
+        self._samp_temp.zero_()
+        self._samp_topp.fill_(1.0)
+        if n:
+            self._samp_temp[:n] = torch.tensor(temperatures, dtype=torch.float32)
+            self._samp_topp[:n] = torch.tensor(top_ps, dtype=torch.float32)
+
+    def draw_uniforms(self, bs: int, generator=None):
+        """Fresh uniform numbers for the next step's draws (queued ahead of the step)."""
+        self._samp_u[:bs].uniform_(0.0, 1.0, generator=generator)
 
     def _decode_batched(self, h, bs, cache_manager):
         """bs > 4 on one GPU: the norm that follows the O and the down projection rides on their

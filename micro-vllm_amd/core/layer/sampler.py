@@ -26,8 +26,10 @@ def greedy(logits: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
 
 
 def sample(logits: torch.Tensor, temperatures: torch.Tensor, top_ps: torch.Tensor, top_k: int,
-           uniforms: torch.Tensor = None, out: torch.Tensor = None, generator=None) -> torch.Tensor:
+           uniforms: torch.Tensor = None, out: torch.Tensor = None, generator=None,
+           greedy_ids: torch.Tensor = None) -> torch.Tensor:
     """logits [bs,V] bf16 -> int64 [bs]; `uniforms` [bs] in [0,1) (drawn here when not given).
+    `greedy_ids` [bs] int64: rows with temperature <= 0 take these without reading the logits.
     No host synchronisation."""
     assert logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2
     assert logits.stride(1) == 1
@@ -43,9 +45,11 @@ def sample(logits: torch.Tensor, temperatures: torch.Tensor, top_ps: torch.Tenso
         out = torch.empty(bs, dtype=torch.long, device=dev)
     assert out.dtype == torch.long and out.is_contiguous() and out.numel() >= bs
     ld = logits.stride(0) if bs > 1 else max(v, logits.stride(0))
-    nv.check("mv_sample_topk_topp", nv.lib().mv_sample_topk_topp(
+    if greedy_ids is not None:
+        assert greedy_ids.dtype == torch.long and greedy_ids.is_contiguous() and greedy_ids.numel() >= bs
+    nv.check("mv_sample_or_greedy", nv.lib().mv_sample_or_greedy(
         logits.data_ptr(), ld, bs, v, temperatures.data_ptr(), top_ps.data_ptr(), int(top_k),
-        uniforms.data_ptr(), out.data_ptr(), nv.stream_ptr()))
+        uniforms.data_ptr(), nv.ptr(greedy_ids), out.data_ptr(), nv.stream_ptr()))
     return out[:bs]
 
 

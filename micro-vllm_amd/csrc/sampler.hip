@@ -192,7 +192,15 @@ __global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __re
                                                           const float* __restrict__ temps,
                                                           const float* __restrict__ top_ps, int top_k,
                                                           const float* __restrict__ uniforms,
+                                                          const int64_t* __restrict__ greedy_ids,
                                                           int64_t* __restrict__ ids) {
+    // A row whose greedy pick is already known (temperature <= 0 and the caller has the argmax)
+    // is done at once: the kernel can then sit in a captured decode step at no cost for greedy
+    // batches.
+    if (greedy_ids != nullptr && !(temps[blockIdx.x] > 0.f)) {  // uniform
+        if (threadIdx.x == 0) ids[blockIdx.x] = greedy_ids[blockIdx.x];
+        return;
+    }
     // Sixteen copies of the 256-bin histogram, one per lane group: logits share a handful of
     // exponents, so with a single copy nearly every lane of a wave adds to the same LDS word and the
     // adds are served one after the other.  A thread also counts runs of equal bins in a register
@@ -403,6 +411,14 @@ __global__ __launch_bounds__(kSmThreads) void sample_kernel(const uint16_t* __re
 extern "C" int mv_sample_topk_topp(const void* logits, int64_t ld, int rows, int n,
                                    const float* temperatures, const float* top_ps, int top_k,
                                    const float* uniforms, int64_t* ids, mv_stream_t stream) {
+    return mv_sample_or_greedy(logits, ld, rows, n, temperatures, top_ps, top_k, uniforms, nullptr, ids,
+                               stream);
+}
+
+extern "C" int mv_sample_or_greedy(const void* logits, int64_t ld, int rows, int n,
+                                   const float* temperatures, const float* top_ps, int top_k,
+                                   const float* uniforms, const int64_t* greedy_ids, int64_t* ids,
+                                   mv_stream_t stream) {
     if (rows == 0 && n > 0) return MV_OK;
     if (!logits || !ids || !temperatures || !top_ps || !uniforms || rows < 0 || n <= 0 || ld < n ||
         top_k <= 0)
@@ -410,7 +426,7 @@ extern "C" int mv_sample_topk_topp(const void* logits, int64_t ld, int rows, int
     if (!mv::aligned16(logits) || (ld % 8) != 0) return MV_ERR_INVALID_ARG;
     if ((n % 8) != 0) return MV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(mv::sample_kernel, dim3(rows), dim3(mv::kSmThreads), 0, (hipStream_t)stream,
-                       (const uint16_t*)logits, ld, n, temperatures, top_ps, top_k, uniforms, ids);
+                       (const uint16_t*)logits, ld, n, temperatures, top_ps, top_k, uniforms, greedy_ids, ids);
     return mv::check_launch();
 }
 

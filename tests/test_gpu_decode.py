@@ -218,3 +218,40 @@ def test_batched_path_with_norms_on_the_slab_reduction_equals_the_per_kernel_pat
     assert torch.equal(a, b)
     for li in range(r1.num_layers):
         assert torch.equal(m1.k_caches[li], m2.k_caches[li]) and torch.equal(m1.v_caches[li], m2.v_caches[li])
+
+
+def test_pick_inside_the_captured_step(mv):
+    """The decode graph ends with the token pick: rows with temperature 0 carry the argmax, the
+    others the draw the stand-alone sampler makes from the same logits, parameters and uniform
+    numbers; rewriting the static parameters between replays changes the next replay only."""
+    from micro_vllm_amd.core.layer.sampler import sample
+
+    bs = 4
+    cfg, runner, mgr, ref, ref_cache = build(mv, "tiny-gqa", n_blocks=24)
+    prefill_random_kv(mgr, ref_cache, [30, 100, 257, 5], seed=4)
+    runner.capture(mgr, batch_sizes=[bs])
+    ids = torch.tensor([1, 2, 3, 4])
+    for sid in range(bs):
+        mgr.append(sid)
+    mgr.cache_batch_data(list(range(bs)), [31, 101, 258, 6])
+    # all greedy (the buffers' initial state)
+    logits = runner.forward(ids.to(DEV), mgr, bs)
+    assert torch.equal(runner.picked_ids(logits), runner.greedy_ids(logits))
+    # rows 1 and 3 draw
+    runner.set_sampling([0.0, 0.9, 0.0, 1.5], [1.0, 0.8, 1.0, 0.95])
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    seen = set()
+    for _ in range(6):
+        runner.draw_uniforms(bs, generator=gen)
+        logits = runner.forward(ids.to(DEV), mgr, bs)     # same inputs: the new key lands on the same slot
+        picked = runner.picked_ids(logits).clone()
+        want = sample(logits, runner._samp_temp[:bs], runner._samp_topp[:bs], runner.decode_top_k,
+                      uniforms=runner._samp_u[:bs].clone())
+        assert torch.equal(picked, want)
+        g = runner.greedy_ids(logits)
+        assert picked[0] == g[0] and picked[2] == g[2]
+        seen.add(int(picked[3]))
+    assert len(seen) > 1, "six draws at temperature 1.5 over 50 candidates never differed"
+    runner.set_sampling([], [])
+    logits = runner.forward(ids.to(DEV), mgr, bs)
+    assert torch.equal(runner.picked_ids(logits), runner.greedy_ids(logits))

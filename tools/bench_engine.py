@@ -38,7 +38,7 @@ eng = InferenceEngine(model=model, tokenizer=Tok(cfg.vocab_size), max_batch_size
                       prefill_timeout=0.0)
 prompts = ["".join(chr(33 + (i * 31 + j * 7) % 90) for j in range(plen)) for i in range(n)]
 
-kinds = {"prefill": [0, 0.0], "decode": [0, 0.0]}
+kinds = {"prefill": [0, 0.0, []], "decode": [0, 0.0, []]}
 orig_step = eng.step
 def timed_step(ctx):
     torch.cuda.synchronize()
@@ -48,12 +48,13 @@ def timed_step(ctx):
     k = kinds[ctx.batch_type if ctx.batch_type in kinds else "decode"]
     k[0] += 1
     k[1] += time.perf_counter() - t
+    k[2].append(time.perf_counter() - t)
     return r
 eng.step = timed_step
 
 for rep in range(2):
     for k in kinds.values():
-        k[0], k[1] = 0, 0.0
+        k[0], k[1], k[2] = 0, 0.0, []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = eng.generate(prompts, max_tokens=gen, temperature=temp, top_p=0.9)
@@ -62,7 +63,9 @@ for rep in range(2):
     ntok = sum(len(v.split()) for v in out.values()) - n * plen   # the decoded text holds the prompt too
     print(f"rep {rep}: {len(out)} requests, {ntok} tokens generated in {dt*1e3:.0f} ms = {ntok/dt:.0f} tok/s "
           f"(prompt {plen}, temperature {temp})")
-    for name, (cnt, tt) in kinds.items():
+    for name, (cnt, tt, each) in kinds.items():
         if cnt:
-            print(f"    {name}: {cnt} steps, {tt*1e3:.0f} ms in step() = {tt/cnt*1e3:.2f} ms/step")
+            each = sorted(each)
+            print(f"    {name}: {cnt} steps, {tt*1e3:.0f} ms in step() = {tt/cnt*1e3:.2f} ms/step "
+                  f"(median {each[len(each)//2]*1e3:.2f}, slowest {each[-1]*1e3:.2f})")
     print(f"    outside step() (scheduler, update_sequences): {(dt - sum(k[1] for k in kinds.values()))*1e3:.0f} ms")
