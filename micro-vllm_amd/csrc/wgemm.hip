@@ -437,7 +437,9 @@ __global__ __launch_bounds__(GW * kWave) void wgemm_dot_kernel(GemmArgs a) {
 template <int MB, int SG>
 __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
     constexpr int U = (SG + MB <= 6) ? 2 : 1;  // k-tiles per stage (register budget)
-    __shared__ __attribute__((aligned(16))) float red[kGW * SG * MB * 64 * 4];
+    // cross-wave reduction buffer [kGW][SG][MB][64 lanes][4]: 8 KiB per (strip, row block) pair,
+    // up to 128 KiB (dynamic: past the 64 KiB a static array may have)
+    extern __shared__ __attribute__((aligned(16))) float red[];
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -512,8 +514,9 @@ __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
             for (int b = 0; b < MB; ++b)
                 *reinterpret_cast<f32x4_t*>(&red[(((wid * SG + sI) * MB + b) * 64 + lane) * 4]) = acc[sI][b];
         __syncthreads();
-        if (threadIdx.x < 64 * MB * SG) {
-            const int sb = threadIdx.x >> 6, l = threadIdx.x & 63;
+        // one wave per (strip, row block) pair; more pairs than waves take a second turn
+        for (int sb = wid; sb < MB * SG; sb += kGW) {
+            const int l = lane;
             const int sI = sb / MB, b = sb - sI * MB;
             const int rr = l & 15, qq = l >> 4;
             const int m = b * 16 + rr;
@@ -757,14 +760,27 @@ static int launch_dot_waves(const GemmArgs& a, int waves, int grid, hipStream_t 
 
 template <int MB, int SG>
 static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((wgemm_mfma_kernel<MB, SG>), dim3(grid), dim3(kGT), 0, s, a);
+    constexpr size_t lds = (size_t)kGW * SG * MB * 64 * 4 * sizeof(float);
+    static_assert(lds <= 128 * 1024, "reduction buffer fits LDS");
+    static bool configured = false;  // per instantiation
+    if (lds > 64 * 1024 && !configured) {
+        hipError_t e = hipFuncSetAttribute((const void*)wgemm_mfma_kernel<MB, SG>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) {
+            set_last_hip_error(e);
+            return MV_ERR_LAUNCH;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL((wgemm_mfma_kernel<MB, SG>), dim3(grid), dim3(kGT), lds, s, a);
     return check_launch();
 }
 
-// strips per workgroup of the MFMA form: SG * MB <= 8 keeps the cross-wave reduction in 64 KiB
+// strips per workgroup of the MFMA form: the cross-wave reduction buffer is 8 KiB per
+// (strip, row block) pair, 128 KiB for four strips of four row blocks
 static int mfma_strip_group(int mb, int nt) {
-    const int most = mb <= 2 ? 4 : 2;
-    if (g_tune_sg == 1 || g_tune_sg == 2 || (g_tune_sg == 4 && most == 4)) return g_tune_sg;
+    const int most = 4;
+    if (g_tune_sg == 1 || g_tune_sg == 2 || g_tune_sg == 4) return g_tune_sg;
     // From sweeps (tools/sweep_mfma_gemv.py).  Two or more row blocks of x: always the widest
     // group - the x traffic out of L2 dominates otherwise (M=32, down projection: 41.7 us with
     // single strips against 25.9 us with groups of four).  One row block: the largest group that
@@ -889,8 +905,8 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
             const int mb = (m + 15) / 16;
             if (mb == 1) rc = sg == 4 ? launch_mfma<1, 4>(a, grid, s) : sg == 2 ? launch_mfma<1, 2>(a, grid, s) : launch_mfma<1, 1>(a, grid, s);
             else if (mb == 2) rc = sg == 4 ? launch_mfma<2, 4>(a, grid, s) : sg == 2 ? launch_mfma<2, 2>(a, grid, s) : launch_mfma<2, 1>(a, grid, s);
-            else if (mb == 3) rc = sg == 2 ? launch_mfma<3, 2>(a, grid, s) : launch_mfma<3, 1>(a, grid, s);
-            else rc = sg == 2 ? launch_mfma<4, 2>(a, grid, s) : launch_mfma<4, 1>(a, grid, s);
+            else if (mb == 3) rc = sg == 4 ? launch_mfma<3, 4>(a, grid, s) : sg == 2 ? launch_mfma<3, 2>(a, grid, s) : launch_mfma<3, 1>(a, grid, s);
+            else rc = sg == 4 ? launch_mfma<4, 4>(a, grid, s) : sg == 2 ? launch_mfma<4, 2>(a, grid, s) : launch_mfma<4, 1>(a, grid, s);
         }
     }
     if (rc != MV_OK) return rc;

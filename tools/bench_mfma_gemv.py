@@ -1,4 +1,5 @@
-"""The four decode projections at batch M through the planner (no sweep): python tools/bench_mfma_gemv.py [M ...]"""
+"""The four decode projections at batch M through the planner (no sweep):
+python tools/bench_mfma_gemv.py [M ...]; MV_BENCH_SG=1|2|4 forces the strips per workgroup."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -8,6 +9,8 @@ from micro_vllm_amd import _native as nv
 from micro_vllm_amd.kernel.linear import StreamedWeight, wgemm, gemm_workspace
 dev = "cuda"
 ws = gemm_workspace(dev, 256 << 20)
+if os.environ.get("MV_BENCH_SG"):
+    nv.lib().mv_wgemm_tune(3, int(os.environ["MV_BENCH_SG"]))
 for m in ([int(a) for a in sys.argv[1:]] or [32]):
     tot = 0.0
     for (n, k, sw) in [(6144, 4096, False), (4096, 4096, False), (28672, 4096, True), (4096, 14336, False)]:
