@@ -607,16 +607,8 @@ static int launch_decode_w(const AttnArgs& a, hipStream_t s) {
     static_assert((size_t)(2 * NS * G + NS * G * D) * sizeof(float) <= 160 * 1024 - 1024, "state merge fits LDS");
     static_assert((size_t)(G * 128 + kAT * 4) * sizeof(float) <= (size_t)(2 * NS * G + NS * G * D) * sizeof(float),
                   "split merge reuses the state arrays");
-    static bool configured = false;
-    if (lds > 64 * 1024 && !configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)paged_attn_decode_kernel<D, G, W>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_last_hip_error(e);
-            return MV_ERR_LAUNCH;
-        }
-        configured = true;
-    }
+    static LdsOptIn opted;  // per instantiation
+    if (int rc = ensure_dynamic_lds((const void*)paged_attn_decode_kernel<D, G, W>, lds, opted)) return rc;
     hipLaunchKernelGGL((paged_attn_decode_kernel<D, G, W>), dim3(a.bs * a.hkv * a.nsplit), dim3(kAT),
                        lds, s, a);
     int rc = check_launch();

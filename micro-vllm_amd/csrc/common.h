@@ -92,6 +92,10 @@ inline int check_launch() {
 }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 int num_cus();  // compute units of the current device (cached)
+// Opt a kernel in to `lds` bytes of dynamic LDS (needed past 64 KiB) on the current device.
+// `done` is the caller's per-kernel record of what each device was last configured for.
+struct LdsOptIn { size_t bytes[64] = {}; };
+int ensure_dynamic_lds(const void* kernel, size_t lds, LdsOptIn& done);
 // wgemm.hip: adds k-slices partial[ks][m][n] (fp32) in order and applies the projection epilogue
 int launch_wgemm_finalize(float* partial, int ksplit, int m, int n, int flags, const uint16_t* bias,
                           const uint16_t* residual, int64_t ld_res, void* y, int64_t ldy, hipStream_t s);

@@ -27,6 +27,20 @@ int num_cus() {
     return cached[dev];
 }
 
+int ensure_dynamic_lds(const void* kernel, size_t lds, LdsOptIn& done) {
+    if (lds <= 64 * 1024) return MV_OK;
+    int dev = 0;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+    if (known && done.bytes[dev] >= lds) return MV_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        set_last_hip_error(e);
+        return MV_ERR_LAUNCH;
+    }
+    if (known) done.bytes[dev] = lds;
+    return MV_OK;
+}
+
 }  // namespace mv
 
 extern "C" {

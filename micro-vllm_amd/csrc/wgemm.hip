@@ -724,16 +724,10 @@ static int launch_dot(const GemmArgs& a, int grid, hipStream_t s) {
     constexpr int U = (M <= 2) ? 4 : 2;  // tiles per stage (register budget: 128 VGPRs at 16 waves per CU)
     const size_t lds = (size_t)M * a.k * 2 + 16 + (size_t)GW * M * 16 * 4;
     if (lds > 160 * 1024) return MV_ERR_UNSUPPORTED;
-    static size_t configured = 0;  // per instantiation
-    if (lds > 64 * 1024 && lds > configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgemm_dot_kernel<M, GW, U, PRO>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) {
-            set_last_hip_error(e);
-            return MV_ERR_LAUNCH;
-        }
-        configured = 160 * 1024;
-    }
+    static LdsOptIn opted;  // per instantiation
+    if (int rc = ensure_dynamic_lds((const void*)wgemm_dot_kernel<M, GW, U, PRO>,
+                                    lds > 64 * 1024 ? 160 * 1024 : lds, opted))
+        return rc;
 #ifdef MV_WGEMM_STAMP
     GemmArgs as = a;
     as.stamp_slot = g_stamp_counter++;
@@ -762,16 +756,8 @@ template <int MB, int SG>
 static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
     constexpr size_t lds = (size_t)kGW * SG * MB * 64 * 4 * sizeof(float);
     static_assert(lds <= 128 * 1024, "reduction buffer fits LDS");
-    static bool configured = false;  // per instantiation
-    if (lds > 64 * 1024 && !configured) {
-        hipError_t e = hipFuncSetAttribute((const void*)wgemm_mfma_kernel<MB, SG>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) {
-            set_last_hip_error(e);
-            return MV_ERR_LAUNCH;
-        }
-        configured = true;
-    }
+    static LdsOptIn opted;  // per instantiation
+    if (int rc = ensure_dynamic_lds((const void*)wgemm_mfma_kernel<MB, SG>, lds, opted)) return rc;
     hipLaunchKernelGGL((wgemm_mfma_kernel<MB, SG>), dim3(grid), dim3(kGT), lds, s, a);
     return check_launch();
 }
