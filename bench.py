@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the prefill leg of the report")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--ragged", action="store_true",
+                    help="context lengths uniform in [256, ctx] (seed 3) instead of ctx for every row")
     ap.add_argument("--shapes", action="store_true", help="per-projection GB/s table on stderr")
     return ap.parse_args()
 
@@ -76,10 +78,13 @@ def build(args, dev, world):
     g.manual_seed(1)
     mgr._k_store.normal_(0.0, 1.0, generator=g)
     mgr._v_store.normal_(0.0, 1.0, generator=g)
+    rng = random.Random(3)
+    ctxs = [rng.randint(min(256, args.ctx), args.ctx) if args.ragged else args.ctx
+            for _ in range(args.bs)]
     for sid in range(args.bs):
-        ok, _ = mgr.alloc(sid, args.ctx)
+        ok, _ = mgr.alloc(sid, ctxs[sid])
         assert ok, "KV pool too small"
-    return cfg, layers, runner, mgr
+    return cfg, layers, runner, mgr, ctxs
 
 
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X
@@ -281,7 +286,7 @@ def main():
 
     pc.setup()
     t_build = time.time()
-    cfg, layers, runner, mgr = build(args, dev, world)
+    cfg, layers, runner, mgr, ctxs = build(args, dev, world)
     bs = args.bs
     if not args.no_graph:
         runner.capture(mgr, batch_sizes=[bs])
@@ -291,12 +296,12 @@ def main():
     seq_ids = list(range(bs))
     ids = torch.randint(0, cfg.vocab_size, (bs,), generator=torch.Generator().manual_seed(0)).to(dev)
     next_ids = torch.zeros(bs, dtype=torch.long, device=dev)
-    pos = args.ctx + 1  # the engine's first decode position after a ctx-token prompt
+    pos = 1  # added to a row's context: the engine's first decode position after a prompt
 
     def step(ids, pos):
         for sid in seq_ids:
             mgr.append(sid)
-        mgr.cache_batch_data(seq_ids, [pos] * bs)
+        mgr.cache_batch_data(seq_ids, [c + pos for c in ctxs])
         logits = runner.forward(ids, mgr, bs)
         return runner.greedy_ids(logits)    # the argmax is the last kernel of the captured step
 
@@ -335,7 +340,7 @@ def main():
         import dataclasses
         full_cfg_bytes = dataclasses.replace(cfg, num_hidden_layers=layers).weight_bytes(world)
     kv_tok = cfg.kv_bytes_per_token(world) * layers // cfg.num_hidden_layers
-    mean_keys = (pos0 + pos - 1) / 2.0 + 1.0
+    mean_keys = sum(ctxs) / bs + (pos0 + pos - 1) / 2.0 + 1.0
     kv_bytes = bs * (mean_keys + 1.0) * kv_tok
     step_bytes = full_cfg_bytes + kv_bytes
     step_gbs = step_bytes / (dt / args.steps) / 1e9
@@ -355,7 +360,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (f"{cfg.name}-shaped random weights, TP={world} bf16, bs={bs}, "
-                         f"seq_len={args.ctx} paged decode (page 256, shuffled block table)"),
+                         f"seq_len={args.ctx}{' ragged: uniform in [256, seq_len]' if args.ragged else ''}"
+                         f" paged decode (page 256, shuffled block table)"),
             "global_batch": bs,
             "seq_len": args.ctx,
             "layers": layers,
