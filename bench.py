@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the prefill leg of the report")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--tail-steps", type=int, default=50,
+                    help="steps timed one by one AFTER the timed region, for the median / p99 step")
     ap.add_argument("--ragged", action="store_true",
                     help="context lengths uniform in [256, ctx] (seed 3) instead of ctx for every row")
     ap.add_argument("--shapes", action="store_true", help="per-projection GB/s table on stderr")
@@ -60,7 +62,7 @@ def build(args, dev, world):
     cfg = SHAPES[args.model]
     layers = args.layers or cfg.num_hidden_layers
     model = build_synthetic_model(cfg, dev, seed=1234, num_layers=layers)
-    total_tokens = args.ctx + args.steps + args.warmup + 8
+    total_tokens = args.ctx + args.steps + args.warmup + args.tail_steps + 8
     blocks_per_seq = (total_tokens + 255) // 256 + 1
     runner = ModelGraphRunner(
         model, layers, cfg.num_attention_heads // world, cfg.head_dim,
@@ -331,6 +333,35 @@ def main():
         dt = float(t.item())
     assert bool(torch.isfinite(runner._logits[:bs].float()).all()), "non-finite logits"
 
+    # ---- outside the timed region: single steps between HIP events (median / p99 latency) ----
+    lat = []
+    for _ in range(args.tail_steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ids = step(ids, pos)
+        e1.record()
+        e1.synchronize()
+        lat.append(e0.elapsed_time(e1))
+        pos += 1
+    lat.sort()
+    # ---- and, with more than one rank, what the 2 x layers all-reduces of a step cost alone ----
+    allreduce_us = None
+    if world > 1:
+        try:
+            buf = torch.zeros(bs, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
+            for _ in range(4):
+                pc.all_reduce(buf)
+            sync_all()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(2 * layers):
+                pc.all_reduce(buf)
+            e1.record()
+            e1.synchronize()
+            allreduce_us = e0.elapsed_time(e1) * 1e3 / (2 * layers)
+        except Exception as e:
+            log(f"[bench] all-reduce timing failed: {e!r}")
+
     ms_per_step = dt / args.steps * 1e3
     tok_s = bs * args.steps / dt
 
@@ -340,7 +371,7 @@ def main():
         import dataclasses
         full_cfg_bytes = dataclasses.replace(cfg, num_hidden_layers=layers).weight_bytes(world)
     kv_tok = cfg.kv_bytes_per_token(world) * layers // cfg.num_hidden_layers
-    mean_keys = sum(ctxs) / bs + (pos0 + pos - 1) / 2.0 + 1.0
+    mean_keys = sum(ctxs) / bs + (pos0 + pos0 + args.steps - 1) / 2.0 + 1.0
     kv_bytes = bs * (mean_keys + 1.0) * kv_tok
     step_bytes = full_cfg_bytes + kv_bytes
     step_gbs = step_bytes / (dt / args.steps) / 1e9
@@ -373,6 +404,13 @@ def main():
         "step_GBps": round(step_gbs, 1),
         "step_hbm_frac": round(step_gbs / HBM_PEAK_GBS, 4),
     }
+    if lat:
+        out["step_ms_median"] = round(lat[len(lat) // 2], 4)
+        out["step_ms_p99"] = round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4)
+    if allreduce_us is not None:
+        # eager launches of the same [bs, hidden] bf16 sum, back to back; the step issues 2 per layer
+        out["allreduce"] = {"us_per_op": round(allreduce_us, 2), "ops_per_step": 2 * layers,
+                            "share_of_step": round(allreduce_us * 2 * layers / (ms_per_step * 1e3), 4)}
 
     if rank == 0:
         try:

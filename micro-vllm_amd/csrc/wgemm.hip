@@ -600,21 +600,36 @@ __global__ __launch_bounds__(256) void wgemm_finalize_norm_kernel(GemmArgs a) {
     const int nvec = a.n >> 3;
     uint4 keep[kPostChunks];
     float ss = 0.f;
+    // Every operand of every chunk is requested before the first is used (chunks past the row end
+    // re-read the last one): the slabs were written by another kernel, so each dependent round of
+    // loads is a trip to memory, and this kernel is nothing but such trips.
+    f32x4_t p_lo[kPostChunks], p_hi[kPostChunks];
+    uint4 b_in[kPostChunks], r_in[kPostChunks], w_in[kPostChunks];
+#pragma unroll
+    for (int j = 0; j < kPostChunks; ++j) {
+        const int n0 = min(threadIdx.x + j * 256, nvec - 1) * 8;
+        const float* p = a.partial + (int64_t)m * a.n + n0;
+        p_lo[j] = *reinterpret_cast<const f32x4_t*>(p);
+        p_hi[j] = *reinterpret_cast<const f32x4_t*>(p + 4);
+        b_in[j] = a.bias ? ld16(a.bias + n0) : make_uint4(0, 0, 0, 0);
+        r_in[j] = a.residual ? ld16(a.residual + (int64_t)m * a.ld_res + n0) : make_uint4(0, 0, 0, 0);
+        w_in[j] = ld16(a.post_ln_w + n0);
+    }
 #pragma unroll
     for (int j = 0; j < kPostChunks; ++j) {
         const int c = threadIdx.x + j * 256;
         if (c < nvec) {
             const int n0 = c * 8;
             f32x4_t lo = (f32x4_t){0.f, 0.f, 0.f, 0.f}, hi = lo;
-            for (int ks = 0; ks < a.ksplit; ++ks) {
+            lo += p_lo[j];
+            hi += p_hi[j];
+            for (int ks = 1; ks < a.ksplit; ++ks) {
                 const float* p = a.partial + ((int64_t)ks * a.m + m) * a.n + n0;
                 lo += *reinterpret_cast<const f32x4_t*>(p);
                 hi += *reinterpret_cast<const f32x4_t*>(p + 4);
             }
             const float acc[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            uint4 bv = make_uint4(0, 0, 0, 0), rv = bv;
-            if (a.bias) bv = ld16(a.bias + n0);
-            if (a.residual) rv = ld16(a.residual + (int64_t)m * a.ld_res + n0);
+            const uint4 bv = b_in[j], rv = r_in[j];
             const uint32_t b4[4] = {bv.x, bv.y, bv.z, bv.w}, r4[4] = {rv.x, rv.y, rv.z, rv.w};
             uint32_t o[4];
 #pragma unroll
@@ -647,7 +662,7 @@ __global__ __launch_bounds__(256) void wgemm_finalize_norm_kernel(GemmArgs a) {
     for (int j = 0; j < kPostChunks; ++j) {
         const int c = threadIdx.x + j * 256;
         if (c < nvec) {
-            const uint4 wv = ld16(a.post_ln_w + c * 8);
+            const uint4 wv = w_in[j];
             const uint32_t s4[4] = {keep[j].x, keep[j].y, keep[j].z, keep[j].w};
             const uint32_t w4[4] = {wv.x, wv.y, wv.z, wv.w};
             uint32_t o[4];
