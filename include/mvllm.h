@@ -170,9 +170,17 @@ size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_split
  * context length; <= 0 means unknown). */
 int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint);
 
+/* Which form of the kernel mv_paged_attn_decode runs for this shape: 0 = dot-product form (scores,
+ * softmax, P and P.V in fp32), 1 = matrix-core form (P rounded to bf16 before P.V, as
+ * flash_attn_with_kvcache does: model_graph.py:161-168 is the call it stands in for); -1 = bad shape.
+ * The two agree within that rounding: |diff| <= 2^-9 * sum_t p_t |v_t| + one bf16 unit. */
+int mv_paged_attn_decode_form(int hq, int hkv, int d, int page);
+
 /* Experiment knobs (no counterpart in the reference): key 0 = merge the KV splits inside the
  * attention kernel (1, default) or in a second launch (0); key 1 = workgroups per CU the
- * automatic split count aims at (1..8; 0 = the built-in rule, default). */
+ * automatic split count aims at (1..8; 0 = the built-in rule, default); key 2 = the matrix-core
+ * form of the kernel (head size 128, 4 or 8 query heads per kv head): 0 = built-in rule,
+ * 1 = never, 2 = whenever it applies. */
 int mv_paged_attn_tune(int key, int value);
 
 /* Single-token paged attention with in-kernel NeoX RoPE and KV append.

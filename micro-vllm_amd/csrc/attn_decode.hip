@@ -22,6 +22,8 @@
 
 namespace mv {
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
 constexpr float kNegBig = -1.0e30f;
 // Arrival counters sit 256 bytes apart: tickets of different (sequence, kv head) pairs are then
 // served by different L2 channels instead of queueing on one cache line.
@@ -98,10 +100,185 @@ static __device__ unsigned long long g_astamp[16 * 4096];
 #define MV_ASTAMP(slot) do {} while (0)
 #endif
 
+// Everything after a workgroup's NS softmax states (m, l, acc[D] per query head) are in LDS as
+// st_m [NS][G] | st_l [NS][G] | st_acc [NS][G][D]: merge them, hand the split's partial over (or
+// write the output when there is one split) and, as the last-arriving split, merge all splits.
+template <int D, int G, int NS, int kAW>
+__device__ __forceinline__ void finish_states(const AttnArgs& a, float* lds, int b, int kvh, int bh,
+                                              int split, int wid, int lane) {
+    constexpr int kAT = kAW * 64;
+    float* st_m = lds;                 // [NS][G]
+    float* st_l = lds + NS * G;        // [NS][G]
+    float* st_acc = lds + 2 * NS * G;  // [NS][G][D]
+    __syncthreads();
+    // One thread per (head, 4 consecutive d): it works out the weights 2^(m_s - max) of its head's
+    // NS states itself (every thread of a head repeats that, which is cheaper than a phase and a
+    // barrier of its own), then adds the states in order.
+    if (threadIdx.x < G * D / 4) {
+        const int g = threadIdx.x / (D / 4), d4 = (threadIdx.x - g * (D / 4)) * 4;
+        float mx = kNegBig;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) mx = fmaxf(mx, st_m[s * G + g]);
+        float lt = 0.f;
+        f32x4_t at = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float w = __builtin_amdgcn_exp2f(st_m[s * G + g] - mx);
+            lt = __builtin_fmaf(st_l[s * G + g], w, lt);
+            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(st_acc + (int64_t)(s * G + g) * D + d4);
+            at[0] = __builtin_fmaf(v[0], w, at[0]);
+            at[1] = __builtin_fmaf(v[1], w, at[1]);
+            at[2] = __builtin_fmaf(v[2], w, at[2]);
+            at[3] = __builtin_fmaf(v[3], w, at[3]);
+        }
+        const int hq = kvh * G + g;
+        f32x4_t val = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (lt > 0.f) {
+            val[0] = at[0] / lt;
+            val[1] = at[1] / lt;
+            val[2] = at[2] / lt;
+            val[3] = at[3] / lt;
+        }
+        if (a.nsplit == 1) {
+            uint2 o2;
+            o2.x = pack_bf16x2(val[0], val[1]);
+            o2.y = pack_bf16x2(val[2], val[3]);
+            *reinterpret_cast<uint2*>(a.out + ((int64_t)b * a.hq + hq) * D + d4) = o2;
+        } else {
+            // write-through (sc1) stores: visible to the merging workgroup without a release fence
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                a.part_o + ((int64_t)b * a.hq + kvh * G) * a.nsplit * D, 0, G * a.nsplit * D * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, val), prs,
+                                                   ((g * a.nsplit + split) * D + d4) * 4, 0, 16 /*sc1*/);
+            if (d4 == 0) {
+                const int64_t pi = ((int64_t)b * a.hq + hq) * a.nsplit + split;
+                __hip_atomic_store(reinterpret_cast<unsigned int*>(a.part_lse + pi),
+                                   __float_as_uint(lt > 0.f ? mx + __builtin_amdgcn_logf(lt) : kNegBig),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    MV_ASTAMP(3);
+    if (a.nsplit == 1 || a.arrive == nullptr) return;
+
+    // ---- last-arriving split of this (b, kv head) merges all splits ---------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
+    __syncthreads();
+    MV_ASTAMP(4);
+    int* flag = reinterpret_cast<int*>(lds);          // the state arrays are dead past the barrier
+    if (threadIdx.x == 0) {
+        // One counter per pair.  (Two levels of counters, groups of eight splits first, measured
+        // slower: 12.3 vs 11.9 us at 32 splits; a ticket costs its round trip, not its queue.)
+        unsigned int* cnt = a.arrive + (int64_t)bh * kArriveStride;
+        const bool last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                          (unsigned)a.nsplit - 1u;
+        if (last)  // back to zero for the next launch: nobody else touches it in this one
+            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+    }
+    __syncthreads();
+    MV_ASTAMP(5);
+    if (!*flag) return;
+    __syncthreads();  // everyone has read the flag before LDS is reused
+    // Every load of handed-off data below is an sc1 (L1-bypassing) load.  Each thread owns one
+    // (head, 4 consecutive d) item and every PARTS-th split of it; its 16-byte loads and the
+    // lse loads are all issued before anything waits, so the merge costs about one memory
+    // round trip.  Partial sums meet in LDS in a fixed order (results are deterministic).
+    constexpr int ITEMS = G * D / 4;
+    constexpr int PARTS = kAT / ITEMS;
+    static_assert(ITEMS * PARTS == kAT, "one (item, part) per thread");
+    constexpr int kMU = PARTS >= 8 ? 4 : 16;  // loads in flight per thread
+    const int ns = a.nsplit;
+    float* wts = lds;                 // [G][nsplit] weights 2^(lse - max) / sum
+    float* psum = lds + G * 128;      // [PARTS][ITEMS][4] (nsplit <= 128)
+    const int item = threadIdx.x % ITEMS, part = threadIdx.x / ITEMS;
+    const int mg = item / (D / 4), md4 = (item - mg * (D / 4)) * 4;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        a.part_o + ((int64_t)b * a.hq + kvh * G) * ns * D, 0, G * ns * D * 4, 0x00020000);
+    auto load_batch = [&](u32x4_t(&v)[kMU], int s0) {
+#pragma unroll
+        for (int j = 0; j < kMU; ++j) {
+            const int sp = min(s0 + j * PARTS, ns - 1);
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((mg * ns + sp) * D + md4) * 4, 0, 16 /*sc1*/);
+        }
+    };
+    // One wave per head turns its log-sum-exps into normalised weights, one split per lane (two
+    // when there are more than 64 splits); the partial loads are in flight meanwhile.
+    float lse0 = kNegBig, lse1 = kNegBig;
+    const int wg0 = wid;  // first head of this wave
+    if (wg0 < G) {
+        const int64_t pi = ((int64_t)b * a.hq + kvh * G + wg0) * ns;
+        if (lane < ns)
+            lse0 = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(a.part_lse + pi + lane),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (lane + 64 < ns)
+            lse1 = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(a.part_lse + pi + lane + 64),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    u32x4_t v0[kMU];
+    load_batch(v0, part);
+    for (int g = wg0; g < G; g += kAW) {
+        if (g != wg0) {  // only when there are more heads than waves
+            const int64_t pi = ((int64_t)b * a.hq + kvh * G + g) * ns;
+            lse0 = lane < ns ? __uint_as_float(__hip_atomic_load(
+                                   reinterpret_cast<unsigned int*>(a.part_lse + pi + lane), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT))
+                             : kNegBig;
+            lse1 = lane + 64 < ns ? __uint_as_float(__hip_atomic_load(
+                                        reinterpret_cast<unsigned int*>(a.part_lse + pi + lane + 64),
+                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                  : kNegBig;
+        }
+        const float mx = wave_max(fmaxf(lse0, lse1));
+        const float w0 = lane < ns ? __builtin_amdgcn_exp2f(lse0 - mx) : 0.f;
+        const float w1 = lane + 64 < ns ? __builtin_amdgcn_exp2f(lse1 - mx) : 0.f;
+        const float sum = wave_sum(w0 + w1);
+        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+        if (lane < ns) wts[g * ns + lane] = w0 * inv;
+        if (lane + 64 < ns) wts[g * ns + lane + 64] = w1 * inv;
+    }
+    MV_ASTAMP(9);
+    __syncthreads();
+    MV_ASTAMP(10);
+    {
+        const float* w = wts + mg * ns;
+        f32x4_t acc_o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        auto consume = [&](const u32x4_t(&v)[kMU], int s0) {
+#pragma unroll
+            for (int j = 0; j < kMU; ++j) {
+                const int sp = s0 + j * PARTS;
+                const float wj = sp < ns ? w[sp] : 0.f;
+                acc_o[0] = __builtin_fmaf(wj, __uint_as_float(v[j].x), acc_o[0]);
+                acc_o[1] = __builtin_fmaf(wj, __uint_as_float(v[j].y), acc_o[1]);
+                acc_o[2] = __builtin_fmaf(wj, __uint_as_float(v[j].z), acc_o[2]);
+                acc_o[3] = __builtin_fmaf(wj, __uint_as_float(v[j].w), acc_o[3]);
+            }
+        };
+        consume(v0, part);
+        for (int s0 = part + PARTS * kMU; s0 < ns; s0 += PARTS * kMU) {
+            u32x4_t v[kMU];
+            load_batch(v, s0);
+            consume(v, s0);
+        }
+        *reinterpret_cast<f32x4_t*>(psum + (part * ITEMS + item) * 4) = acc_o;
+    }
+    __syncthreads();
+    MV_ASTAMP(6);
+    if (threadIdx.x < ITEMS) {
+        f32x4_t t = *reinterpret_cast<const f32x4_t*>(psum + item * 4);
+#pragma unroll
+        for (int p = 1; p < PARTS; ++p) t += *reinterpret_cast<const f32x4_t*>(psum + (p * ITEMS + item) * 4);
+        uint2 o2;
+        o2.x = pack_bf16x2(t[0], t[1]);
+        o2.y = pack_bf16x2(t[2], t[3]);
+        *reinterpret_cast<uint2*>(a.out + ((int64_t)b * a.hq + kvh * G + mg) * D + md4) = o2;
+    }
+    MV_ASTAMP(7);
+}
+
 template <int D, int G, int W>
 __global__ __launch_bounds__(W * 64) void paged_attn_decode_kernel(AttnArgs a) {
     constexpr int kAW = W;          // waves per workgroup
-    constexpr int kAT = W * 64;     // threads per workgroup
     constexpr int kAC = 4;          // row loads per wave per pipeline stage
     constexpr int LPR = D / 8;      // lanes per row
     constexpr int RPI = 64 / LPR;   // rows per wave instruction
@@ -364,170 +541,278 @@ __global__ __launch_bounds__(W * 64) void paged_attn_decode_kernel(AttnArgs a) {
         *reinterpret_cast<f32x4_t*>(dst) = (f32x4_t){acc[g][0], acc[g][1], acc[g][2], acc[g][3]};
         *reinterpret_cast<f32x4_t*>(dst + 4) = (f32x4_t){acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
     }
-    __syncthreads();
-    // One thread per (head, 4 consecutive d): it works out the weights 2^(m_s - max) of its head's
-    // NS states itself (every thread of a head repeats that, which is cheaper than a phase and a
-    // barrier of its own), then adds the states in order.
-    if (threadIdx.x < G * D / 4) {
-        const int g = threadIdx.x / (D / 4), d4 = (threadIdx.x - g * (D / 4)) * 4;
+    finish_states<D, G, NS, kAW>(a, lds, b, kvh, bh, split, wid, lane);
+}
+
+// ------------------------------------------------------------ matrix-core form (D = 128, G >= 4)
+// The dot-product kernel above spends its time in the vector unit once four or more query heads
+// share a kv head (G dots, G lane reductions and G x 8 multiply-adds per row).  Here a wave takes
+// 32 rows at a time and gives both products to the matrix cores:
+//   S^T[t][g] = K[t][:] . Q[g][:]      A = 16 key rows as loaded (lane (r, q): row r, 8 values of
+//                                      k-slice q), B = the rotated query heads, padded to 16
+//   O^T[d][g] += V^T[d][t] . P^T[t][g] A = values transposed through LDS, B = P rounded to bf16
+// The k index of the second product is the order the first one leaves its scores in (lane (g, q')
+// holds rows 4q'..4q'+3 of both 16-row blocks), and the values are read in that order, so P never
+// moves between lanes.  A lane reads two neighbouring d of a value row as one dword and gives the
+// low halves to one product and the high halves to another: output row m of pair p is
+// d = 32p + 2m (+1), which leaves lane (g, q') with O[g][32p + 8q' .. + 7].
+// The softmax state is per wave (4 per workgroup); everything after it is finish_states.
+constexpr int kMRows = 32;        // rows per wave per stage
+constexpr int kMVRow = 272;       // bytes per staged value row (256 + 16: conflict-free both ways)
+
+template <int G>
+__global__ __launch_bounds__(256) void paged_attn_decode_mfma_kernel(AttnArgs a) {
+    constexpr int D = 128, kAW = 4, NS = kAW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    unsigned char* vst = reinterpret_cast<unsigned char*>(lds) + wid * (kMRows * kMVRow);
+    MV_ASTAMP(0);
+
+    const int split = blockIdx.x % a.nsplit;
+    const int bh = blockIdx.x / a.nsplit;
+    const int kvh = bh % a.hkv, b = bh / a.hkv;
+    const bool last_split = (split == a.nsplit - 1);
+
+    const int pos = a.seqlens[b];
+    const int32_t* bt = a.block_table + (int64_t)b * a.bt_stride;
+    const int64_t row_stride = (int64_t)a.hkv * D;
+    const int64_t head_off = (int64_t)kvh * D;
+
+    // 32-row blocks of the sequence are dealt round robin over (split, wave): which rows a wave
+    // reads does not depend on the sequence length, only how many of them count.
+    const int blk_first = split * kAW + wid, blk_step = a.nsplit * kAW;
+    auto page_of = [&](int c) {
+        const int t0 = (blk_first + c * blk_step) * kMRows;
+        return bt[min(t0 >> a.page_shift, a.bt_stride - 1)];
+    };
+    int pgA = page_of(0), pgB = page_of(1);   // pages of the current and the next stage
+
+    // ---- query heads (B operand: lane (r, q) = head r, 8 values at 32 kk + 8 q), new k / v ----
+    const bool rotate = (a.rot_cos != nullptr);
+    const int gq = r < G ? r : 0;
+    const uint16_t* qh = a.q + (int64_t)b * a.q_stride_b + (int64_t)(kvh * G + gq) * D + q * 8;
+    const uint16_t* kh = a.k_new + (int64_t)b * a.kv_stride_b + (int64_t)kvh * D + q * 8;
+    const uint16_t* vh = a.v_new + (int64_t)b * a.kv_stride_b + (int64_t)kvh * D + q * 8;
+    uint4 qx[4], kx[4], vnew[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qx[kk] = ld16(qh + kk * 32);
+        kx[kk] = ld16(kh + kk * 32);
+        vnew[kk] = ld16(vh + kk * 32);
+    }
+
+    auto load_k = [&](uint4(&kb)[8], int pg, int c) {
+        const int t0 = (blk_first + c * blk_step) * kMRows;
+        const bool page_ok = pg >= 0 && pg < a.num_pages;
+        const int64_t row0 = ((int64_t)(page_ok ? pg : 0) << a.page_shift) + (t0 & (a.page - 1));
+        const uint16_t* kp0 = a.k_cache + (row0 + r) * row_stride + head_off + q * 8;
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) kb[blk * 4 + kk] = ld16(kp0 + blk * 16 * row_stride + kk * 32);
+    };
+    auto load_v = [&](uint4(&vb)[8], int pg, int c) {
+        const int t0 = (blk_first + c * blk_step) * kMRows;
+        const bool page_ok = pg >= 0 && pg < a.num_pages;
+        const int64_t row0 = ((int64_t)(page_ok ? pg : 0) << a.page_shift) + (t0 & (a.page - 1));
+        const uint16_t* vp0 = a.v_cache + (row0 + q) * row_stride + head_off + r * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) vb[i] = ld16(vp0 + i * 4 * row_stride);
+    };
+    // One stage of rows in registers: its value rows go to LDS and its key rows into the matrix
+    // unit at the top of a pass, and the next stage is requested into the same registers right
+    // behind them, so it has the softmax and the second product to arrive (other waves of the CU
+    // cover the rest).  Two register stages cost 64 more registers and a wave per SIMD.
+    uint4 kR[8], vR[8];
+    load_k(kR, pgA, 0);
+    load_v(vR, pgA, 0);
+    uint4 cosv[2], sinv[2];
+    cosv[0] = cosv[1] = sinv[0] = sinv[1] = make_uint4(0, 0, 0, 0);
+    if (rotate) {
+        const int rp = min(max(pos, 0), a.rot_max_pos - 1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            cosv[h] = ld16(a.rot_cos + (int64_t)rp * (D / 2) + h * 32 + q * 8);
+            sinv[h] = ld16(a.rot_sin + (int64_t)rp * (D / 2) + h * 32 + q * 8);
+        }
+    }
+    const int nblk = (max(pos, 0) + kMRows - 1) / kMRows;
+    const int nchunk = nblk > blk_first ? (nblk - blk_first + blk_step - 1) / blk_step : 0;
+
+    // pieces kk and kk ^ 2 are half a head apart: the rotation needs no other lane
+    bf16x8_t qf[4];
+    uint32_t kp[4][4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        uint32_t o[4];
+        if (rotate) {
+            rope8(qx[kk], qx[kk ^ 2], cosv[kk & 1], sinv[kk & 1], kk < 2, o);
+            rope8(kx[kk], kx[kk ^ 2], cosv[kk & 1], sinv[kk & 1], kk < 2, kp[kk]);
+        } else {
+            o[0] = qx[kk].x; o[1] = qx[kk].y; o[2] = qx[kk].z; o[3] = qx[kk].w;
+            kp[kk][0] = kx[kk].x; kp[kk][1] = kx[kk].y; kp[kk][2] = kx[kk].z; kp[kk][3] = kx[kk].w;
+        }
+        const uint32_t keep = r < G ? 0xFFFFFFFFu : 0u;   // padding heads score zero
+        qf[kk] = __builtin_bit_cast(bf16x8_t, make_uint4(o[0] & keep, o[1] & keep, o[2] & keep, o[3] & keep));
+    }
+    // append: the last split owns the new row; the four lanes with r == 0 of wave 0 hold all of it
+    if (last_split && wid == 0 && r == 0) {
+        const int pi = pos >> a.page_shift;
+        if (pos >= 0 && pi < a.bt_stride) {
+            const int pg = bt[pi];
+            if (pg >= 0 && pg < a.num_pages) {
+                const int64_t off =
+                    (((int64_t)pg << a.page_shift) + (pos & (a.page - 1))) * row_stride + head_off + q * 8;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    st16(a.k_cache + off + kk * 32, make_uint4(kp[kk][0], kp[kk][1], kp[kk][2], kp[kk][3]));
+                    st16(a.v_cache + off + kk * 32, vnew[kk]);
+                }
+            }
+        }
+    }
+
+    // ---- state of this wave: lane (g = r, q') holds m[g], a quarter of l[g], O[g][32p + 8q' ..] ----
+    float m = kNegBig, l = 0.f;
+    f32x4_t oacc[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) oacc[p][0] = oacc[p][1] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    // The new row comes from registers and goes in FIRST (the order of rows does not matter to the
+    // running softmax), so that its registers are free during the loop: wave 0 of the last split.
+    if (last_split && wid == 0) {  // wave-uniform
+        float d = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint4 qv = __builtin_bit_cast(uint4, qf[kk]);
+            d = dot2_bf16(qv.x, kp[kk][0], d);
+            d = dot2_bf16(qv.y, kp[kk][1], d);
+            d = dot2_bf16(qv.z, kp[kk][2], d);
+            d = dot2_bf16(qv.w, kp[kk][3], d);
+        }
+        d += __shfl_xor(d, 16);
+        d += __shfl_xor(d, 32);
+        m = d * a.scale_log2;
+        l = q == 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t vs[4] = {vnew[p].x, vnew[p].y, vnew[p].z, vnew[p].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                oacc[p][0][j] = bf16_lo(vs[j]);
+                oacc[p][1][j] = bf16_hi(vs[j]);
+            }
+        }
+    }
+
+    auto absorb = [&](uint4(&kb)[8], uint4(&vb)[8], int pg, int pg_next, int c, bool more) {
+        const int t0 = (blk_first + c * blk_step) * kMRows;
+        const bool page_ok = pg >= 0 && pg < a.num_pages;
+        // values of rows that do not count may be any bit pattern: zero them on the way into LDS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 4 + q;
+            const uint32_t keep = (page_ok && t0 + row < pos) ? 0xFFFFFFFFu : 0u;
+            *reinterpret_cast<uint4*>(vst + row * kMVRow + r * 16) =
+                make_uint4(vb[i].x & keep, vb[i].y & keep, vb[i].z & keep, vb[i].w & keep);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_v(vb, pg_next, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4_t s0 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kb[kk]), qf[kk], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, kb[4 + kk]), qf[kk], s1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) load_k(kb, pg_next, c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // lane (g, q'): s0[j] = row t0 + 4q' + j, s1[j] = row t0 + 16 + 4q' + j
+        float sc[8];
+        bool ok[8];
         float mx = kNegBig;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) mx = fmaxf(mx, st_m[s * G + g]);
-        float lt = 0.f;
-        f32x4_t at = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) {
+            const int t = t0 + (j < 4 ? 0 : 16) + 4 * q + (j & 3);
+            ok[j] = page_ok && t < pos;
+            sc[j] = (j < 4 ? s0[j & 3] : s1[j & 3]) * a.scale_log2;
+            mx = ok[j] ? fmaxf(mx, sc[j]) : mx;
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, m);
+        const float alpha = __builtin_amdgcn_exp2f(m - mx);
+        m = mx;
+        float pv[8], psum = 0.f;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const float w = __builtin_amdgcn_exp2f(st_m[s * G + g] - mx);
-            lt = __builtin_fmaf(st_l[s * G + g], w, lt);
-            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(st_acc + (int64_t)(s * G + g) * D + d4);
-            at[0] = __builtin_fmaf(v[0], w, at[0]);
-            at[1] = __builtin_fmaf(v[1], w, at[1]);
-            at[2] = __builtin_fmaf(v[2], w, at[2]);
-            at[3] = __builtin_fmaf(v[3], w, at[3]);
+        for (int j = 0; j < 8; ++j) {
+            pv[j] = ok[j] ? __builtin_amdgcn_exp2f(sc[j] - mx) : 0.f;
+            psum += pv[j];
         }
-        const int hq = kvh * G + g;
-        f32x4_t val = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        if (lt > 0.f) {
-            val[0] = at[0] / lt;
-            val[1] = at[1] / lt;
-            val[2] = at[2] / lt;
-            val[3] = at[3] / lt;
+        l = l * alpha + psum;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            oacc[p][0] *= alpha;
+            oacc[p][1] *= alpha;
         }
-        if (a.nsplit == 1) {
-            uint2 o2;
-            o2.x = pack_bf16x2(val[0], val[1]);
-            o2.y = pack_bf16x2(val[2], val[3]);
-            *reinterpret_cast<uint2*>(a.out + ((int64_t)b * a.hq + hq) * D + d4) = o2;
-        } else {
-            // write-through (sc1) stores: visible to the merging workgroup without a release fence
-            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-                a.part_o + ((int64_t)b * a.hq + kvh * G) * a.nsplit * D, 0, G * a.nsplit * D * 4, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, val), prs,
-                                                   ((g * a.nsplit + split) * D + d4) * 4, 0, 16 /*sc1*/);
-            if (d4 == 0) {
-                const int64_t pi = ((int64_t)b * a.hq + hq) * a.nsplit + split;
-                __hip_atomic_store(reinterpret_cast<unsigned int*>(a.part_lse + pi),
-                                   __float_as_uint(lt > 0.f ? mx + __builtin_amdgcn_logf(lt) : kNegBig),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bf16x8_t pf = __builtin_bit_cast(
+            bf16x8_t, make_uint4(pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3]),
+                                 pack_bf16x2(pv[4], pv[5]), pack_bf16x2(pv[6], pv[7])));
+        __builtin_amdgcn_wave_barrier();  // LDS operations of a wave run in order: no wait needed
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = (i < 4 ? 0 : 16) + 4 * q + (i & 3);
+                w[i] = *reinterpret_cast<const uint32_t*>(vst + row * kMVRow + (16 * p + r) * 4);
             }
-        }
-    }
-    MV_ASTAMP(3);
-    if (a.nsplit == 1 || a.arrive == nullptr) return;
-
-    // ---- last-arriving split of this (b, kv head) merges all splits ---------------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its stores
-    __syncthreads();
-    MV_ASTAMP(4);
-    int* flag = reinterpret_cast<int*>(lds);          // the state arrays are dead past the barrier
-    if (threadIdx.x == 0) {
-        // One counter per pair.  (Two levels of counters, groups of eight splits first, measured
-        // slower: 12.3 vs 11.9 us at 32 splits; a ticket costs its round trip, not its queue.)
-        unsigned int* cnt = a.arrive + (int64_t)bh * kArriveStride;
-        const bool last = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                          (unsigned)a.nsplit - 1u;
-        if (last)  // back to zero for the next launch: nobody else touches it in this one
-            __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *flag = last;
-    }
-    __syncthreads();
-    MV_ASTAMP(5);
-    if (!*flag) return;
-    __syncthreads();  // everyone has read the flag before LDS is reused
-    // Every load of handed-off data below is an sc1 (L1-bypassing) load.  Each thread owns one
-    // (head, 4 consecutive d) item and every PARTS-th split of it; its 16-byte loads and the
-    // lse loads are all issued before anything waits, so the merge costs about one memory
-    // round trip.  Partial sums meet in LDS in a fixed order (results are deterministic).
-    constexpr int ITEMS = G * D / 4;
-    constexpr int PARTS = kAT / ITEMS;
-    static_assert(ITEMS * PARTS == kAT, "one (item, part) per thread");
-    constexpr int kMU = PARTS >= 8 ? 4 : 16;  // loads in flight per thread
-    const int ns = a.nsplit;
-    float* wts = lds;                 // [G][nsplit] weights 2^(lse - max) / sum
-    float* psum = lds + G * 128;      // [PARTS][ITEMS][4] (nsplit <= 128)
-    const int item = threadIdx.x % ITEMS, part = threadIdx.x / ITEMS;
-    const int mg = item / (D / 4), md4 = (item - mg * (D / 4)) * 4;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        a.part_o + ((int64_t)b * a.hq + kvh * G) * ns * D, 0, G * ns * D * 4, 0x00020000);
-    auto load_batch = [&](u32x4_t(&v)[kMU], int s0) {
+            uint32_t lo[4], hi[4];
 #pragma unroll
-        for (int j = 0; j < kMU; ++j) {
-            const int sp = min(s0 + j * PARTS, ns - 1);
-            v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((mg * ns + sp) * D + md4) * 4, 0, 16 /*sc1*/);
+            for (int j = 0; j < 4; ++j) {
+                lo[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x05040100u);
+                hi[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);
+            }
+            oacc[p][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, make_uint4(lo[0], lo[1], lo[2], lo[3])), pf, oacc[p][0], 0, 0, 0);
+            oacc[p][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8_t, make_uint4(hi[0], hi[1], hi[2], hi[3])), pf, oacc[p][1], 0, 0, 0);
         }
+        __builtin_amdgcn_wave_barrier();
     };
-    // One wave per head turns its log-sum-exps into normalised weights, one split per lane (two
-    // when there are more than 64 splits); the partial loads are in flight meanwhile.
-    float lse0 = kNegBig, lse1 = kNegBig;
-    const int wg0 = wid;  // first head of this wave
-    if (wg0 < G) {
-        const int64_t pi = ((int64_t)b * a.hq + kvh * G + wg0) * ns;
-        if (lane < ns)
-            lse0 = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(a.part_lse + pi + lane),
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        if (lane + 64 < ns)
-            lse1 = __uint_as_float(__hip_atomic_load(reinterpret_cast<unsigned int*>(a.part_lse + pi + lane + 64),
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+
+    MV_ASTAMP(1);
+    for (int c = 0; c < nchunk; ++c) {
+        const int pgC = page_of(c + 2);
+        absorb(kR, vR, pgA, pgB, c, c + 1 < nchunk);
+        pgA = pgB;
+        pgB = pgC;
     }
-    u32x4_t v0[kMU];
-    load_batch(v0, part);
-    for (int g = wg0; g < G; g += kAW) {
-        if (g != wg0) {  // only when there are more heads than waves
-            const int64_t pi = ((int64_t)b * a.hq + kvh * G + g) * ns;
-            lse0 = lane < ns ? __uint_as_float(__hip_atomic_load(
-                                   reinterpret_cast<unsigned int*>(a.part_lse + pi + lane), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT))
-                             : kNegBig;
-            lse1 = lane + 64 < ns ? __uint_as_float(__hip_atomic_load(
-                                        reinterpret_cast<unsigned int*>(a.part_lse + pi + lane + 64),
-                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                  : kNegBig;
-        }
-        const float mx = wave_max(fmaxf(lse0, lse1));
-        const float w0 = lane < ns ? __builtin_amdgcn_exp2f(lse0 - mx) : 0.f;
-        const float w1 = lane + 64 < ns ? __builtin_amdgcn_exp2f(lse1 - mx) : 0.f;
-        const float sum = wave_sum(w0 + w1);
-        const float inv = sum > 0.f ? 1.0f / sum : 0.f;
-        if (lane < ns) wts[g * ns + lane] = w0 * inv;
-        if (lane + 64 < ns) wts[g * ns + lane + 64] = w1 * inv;
-    }
-    MV_ASTAMP(9);
+
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+
+    // ---- the four wave states into LDS (over the value staging: everybody is done with it) ----
+    MV_ASTAMP(2);
     __syncthreads();
-    MV_ASTAMP(10);
-    {
-        const float* w = wts + mg * ns;
-        f32x4_t acc_o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        auto consume = [&](const u32x4_t(&v)[kMU], int s0) {
-#pragma unroll
-            for (int j = 0; j < kMU; ++j) {
-                const int sp = s0 + j * PARTS;
-                const float wj = sp < ns ? w[sp] : 0.f;
-                acc_o[0] = __builtin_fmaf(wj, __uint_as_float(v[j].x), acc_o[0]);
-                acc_o[1] = __builtin_fmaf(wj, __uint_as_float(v[j].y), acc_o[1]);
-                acc_o[2] = __builtin_fmaf(wj, __uint_as_float(v[j].z), acc_o[2]);
-                acc_o[3] = __builtin_fmaf(wj, __uint_as_float(v[j].w), acc_o[3]);
-            }
-        };
-        consume(v0, part);
-        for (int s0 = part + PARTS * kMU; s0 < ns; s0 += PARTS * kMU) {
-            u32x4_t v[kMU];
-            load_batch(v, s0);
-            consume(v, s0);
+    float* st_m = lds;
+    float* st_l = lds + NS * G;
+    float* st_acc = lds + 2 * NS * G;
+    if (r < G) {
+        if (q == 0) {
+            st_m[wid * G + r] = m;
+            st_l[wid * G + r] = l;
         }
-        *reinterpret_cast<f32x4_t*>(psum + (part * ITEMS + item) * 4) = acc_o;
-    }
-    __syncthreads();
-    MV_ASTAMP(6);
-    if (threadIdx.x < ITEMS) {
-        f32x4_t t = *reinterpret_cast<const f32x4_t*>(psum + item * 4);
 #pragma unroll
-        for (int p = 1; p < PARTS; ++p) t += *reinterpret_cast<const f32x4_t*>(psum + (p * ITEMS + item) * 4);
-        uint2 o2;
-        o2.x = pack_bf16x2(t[0], t[1]);
-        o2.y = pack_bf16x2(t[2], t[3]);
-        *reinterpret_cast<uint2*>(a.out + ((int64_t)b * a.hq + kvh * G + mg) * D + md4) = o2;
+        for (int p = 0; p < 4; ++p) {
+            float* dst = st_acc + (int64_t)(wid * G + r) * D + 32 * p + 8 * q;
+            *reinterpret_cast<f32x4_t*>(dst) = (f32x4_t){oacc[p][0][0], oacc[p][1][0], oacc[p][0][1], oacc[p][1][1]};
+            *reinterpret_cast<f32x4_t*>(dst + 4) = (f32x4_t){oacc[p][0][2], oacc[p][1][2], oacc[p][0][3], oacc[p][1][3]};
+        }
     }
-    MV_ASTAMP(7);
+    finish_states<D, G, NS, kAW>(a, lds, b, kvh, bh, split, wid, lane);
 }
 
 // Second-launch form of the split merge (used when the arrival counters are unavailable or
@@ -627,8 +912,36 @@ static int launch_decode(const AttnArgs& a, hipStream_t s) {
     return launch_decode_w<D, G, 4>(a, s);
 }
 
+template <int G>
+static int launch_decode_mfma(const AttnArgs& a, hipStream_t s) {
+    constexpr int D = 128, NS = 4, kAT = 256;
+    constexpr size_t stage = (size_t)4 * kMRows * kMVRow;
+    constexpr size_t state = (size_t)(2 * NS * G + NS * G * D) * sizeof(float);
+    constexpr size_t merge = (size_t)(G * 128 + kAT * 4) * sizeof(float);
+    constexpr size_t lds = stage > state ? (stage > merge ? stage : merge) : (state > merge ? state : merge);
+    static_assert(lds <= 64 * 1024, "no opt-in needed");
+    hipLaunchKernelGGL((paged_attn_decode_mfma_kernel<G>), dim3(a.bs * a.hkv * a.nsplit), dim3(kAT), lds, s, a);
+    int rc = check_launch();
+    if (rc != MV_OK || a.nsplit == 1 || a.arrive != nullptr) return rc;
+    hipLaunchKernelGGL((paged_attn_combine_kernel<D, G, 4>), dim3(a.bs * a.hq), dim3(D), 0, s,
+                       a.part_lse, a.part_o, a.out, a.nsplit);
+    return check_launch();
+}
+
+static int g_tune_mfma = 0;  // matrix-core form: 0 = built-in rule, 1 = never, 2 = whenever it applies
+
+// Measured on MI355X (tools/sweep_attn_mfma.py): with eight query heads per kv head the
+// matrix-core form wins everywhere (8 sequences x 1 kv head at ctx 8192: 16.1 us against 21.6);
+// with four the two forms are within 3 % of each other at every batch size (both stop at about
+// 5.6 TB/s), and the dot-product form keeps P in fp32.
+static bool use_mfma_form(int d, int g, int page) {
+    if (d != 128 || (g != 4 && g != 8) || (page % kMRows) != 0 || g_tune_mfma == 1) return false;
+    return g_tune_mfma == 2 || g == 8;
+}
+
 template <int D>
 static int dispatch_g(const AttnArgs& a, int g, hipStream_t s) {
+    if (use_mfma_form(D, g, a.page)) return g == 4 ? launch_decode_mfma<4>(a, s) : launch_decode_mfma<8>(a, s);
     switch (g) {
         case 1: return launch_decode<D, 1>(a, s);
         case 2: return launch_decode<D, 2>(a, s);
@@ -658,8 +971,9 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint) {
     // workgroup reads all of them, so the count aims at one workgroup per CU: measured on MI355X,
     // bs=1 / 8 kv heads runs 12.3 us at 32 splits against 14.8 at 16 and 14.9 at 64 for ctx 4096,
     // 16.8 / 21.6 / 17.4 us for ctx 8192; 8 sequences x 1 kv head at ctx 8192 run 23.3 us at 32
-    // splits, 29.7 at 16 and 37.6 at 64.  Large batches, where that rule gives a single split, are
-    // faster with two workgroups per CU (bs=32: 2 splits).
+    // splits, 29.7 at 16 and 37.6 at 64.  Large batches get what the same rule gives them: 16
+    // sequences x 8 kv heads at ctx 4096 run 53.2 us at 2 splits against 58.1 at 4, 32 sequences
+    // 94.9 us unsplit against 105.0 at 2.
     const int pairs = bs * hkv;
     const int per_cu = mv::g_tune_target_blocks_x;  // 0 = the rule above
     const int cus = mv::num_cus();
@@ -667,8 +981,7 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint) {
     if (per_cu > 0) {
         ns = (per_cu * cus + pairs - 1) / pairs;
     } else {
-        const int one = (cus + pairs - 1) / pairs, two = (2 * cus + pairs - 1) / pairs;
-        ns = two <= 4 ? two : one;
+        ns = (cus + pairs - 1) / pairs;
     }
     if (ctx_hint > 0) {
         // rows are dealt out in chunks of 64 (d = 128) or 128 (d = 64): no more splits than chunks
@@ -681,6 +994,11 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint) {
     return ns;
 }
 
+int mv_paged_attn_decode_form(int hq, int hkv, int d, int page) {
+    if (hq <= 0 || hkv <= 0 || hq % hkv) return -1;
+    return mv::use_mfma_form(d, hq / hkv, page) ? 1 : 0;
+}
+
 /* Experiment knobs: key 0 = merge splits inside the kernel (1) or in a second launch (0);
  * key 1 = workgroups per CU the automatic split count aims at (0 = built-in rule). */
 int mv_paged_attn_tune(int key, int value) {
@@ -690,6 +1008,10 @@ int mv_paged_attn_tune(int key, int value) {
     }
     if (key == 1 && value >= 0 && value <= 8) {
         mv::g_tune_target_blocks_x = value;
+        return MV_OK;
+    }
+    if (key == 2 && value >= 0 && value <= 2) {
+        mv::g_tune_mfma = value;
         return MV_OK;
     }
     return MV_ERR_INVALID_ARG;

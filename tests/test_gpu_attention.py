@@ -5,9 +5,11 @@ vector upstream): the oracle restates the documented contract.
 Checked per case:
   * block-table indexing and the KV append (rotated k, raw v, every untouched slot): bit exact;
   * output vs the exact-softmax oracle: 1e-5 absolute + one bf16 unit in the last place (both
-    sides round the output to bf16) - this is the tight check of the kernel's arithmetic;
-  * output vs the oracle that also rounds P to bf16 (what a tensor-core kernel does): the
-    path's stated 1e-3 + one bf16 unit + that rounding's own bound 2^-9 * sum_t p_t |v_t|."""
+    sides round the output to bf16) - this is the tight check of the kernel's arithmetic, made
+    whenever the dot-product form of the kernel runs (mv_paged_attn_decode_form == 0);
+  * output vs the oracle that also rounds P to bf16 (what a tensor-core kernel does, and what the
+    matrix-core form of the kernel does): the path's stated 1e-3 + one bf16 unit + that
+    rounding's own bound 2^-9 * sum_t p_t |v_t|."""
 import pytest
 import torch
 
@@ -43,13 +45,23 @@ def make_case(B, Hq, Hkv, D, page, ctxs, seed, n_pages=None, rotary=True, pad_co
     return dict(q=q, k=k, v=v, k_cache=k_cache, v_cache=v_cache, bt=bt, seqlens=seqlens, cos=cos, sin=sin)
 
 
+def dot_form(case):
+    """True when the library runs its fp32-P kernel for this case's shape."""
+    from micro_vllm_amd import _native as nv
+    _, page, hkv, d = case["k_cache"].shape
+    form = nv.lib().mv_paged_attn_decode_form(case["q"].shape[2], hkv, d, page)
+    assert form in (0, 1)
+    return form == 0
+
+
 def check_output(got, case, what="", scale=None):
     """Both oracle forms (see the module docstring)."""
     got = got.reshape(case["q"].shape)
-    exact = flash_attn_with_kvcache_ref(case["q"], case["k_cache"].clone(), case["v_cache"].clone(),
-                                        case["k"], case["v"], case["cos"], case["sin"], case["seqlens"],
-                                        case["bt"], softmax_scale=scale, p_bf16=False)
-    assert_close_bf16(got, exact, atol=1e-5, rtol=2 ** -7, what=what + " (exact softmax)")
+    if dot_form(case):
+        exact = flash_attn_with_kvcache_ref(case["q"], case["k_cache"].clone(), case["v_cache"].clone(),
+                                            case["k"], case["v"], case["cos"], case["sin"], case["seqlens"],
+                                            case["bt"], softmax_scale=scale, p_bf16=False)
+        assert_close_bf16(got, exact, atol=1e-5, rtol=2 ** -7, what=what + " (exact softmax)")
     faithful, bound = flash_attn_with_kvcache_ref(
         case["q"], case["k_cache"].clone(), case["v_cache"].clone(), case["k"], case["v"], case["cos"],
         case["sin"], case["seqlens"], case["bt"], softmax_scale=scale, p_bf16=True, return_p_bound=True)
@@ -200,7 +212,7 @@ def test_in_kernel_merge_equals_second_kernel_merge(mv):
         check_output(lst[0], case, what=f"merge splits={splits}")
 
 
-@pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 2), (64, 8, 2)])
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 2), (64, 8, 2), (128, 8, 1)])
 def test_slots_that_do_not_count_may_hold_anything(mv, D, Hq, Hkv):
     """The kernel requests the first rows of every split before it knows the sequence length, so it
     reads slots at and past the length and pages no block table points to.  Whatever they hold
@@ -228,3 +240,82 @@ def test_slots_that_do_not_count_may_hold_anything(mv, D, Hq, Hkv):
         keep = ~used[:, :, None, None].expand_as(dirty["k_cache"])
         assert torch.equal(kc.cpu().view(torch.int16)[keep], dirty["k_cache"].view(torch.int16)[keep])
         assert torch.equal(vc.cpu().view(torch.int16)[keep], dirty["v_cache"].view(torch.int16)[keep])
+
+
+@pytest.fixture
+def matrix_core_form(mv):
+    """Force the matrix-core form of the kernel wherever it applies (D = 128, 4 or 8 query heads per
+    kv head) for the duration of a test."""
+    from micro_vllm_amd import _native as nv
+    assert nv.lib().mv_paged_attn_tune(2, 2) == 0
+    yield
+    assert nv.lib().mv_paged_attn_tune(2, 0) == 0
+
+
+@pytest.mark.parametrize("Hq,Hkv", [(8, 2), (8, 1), (16, 2), (4, 1)])
+@pytest.mark.parametrize("splits", [1, 3, 0, 64])
+def test_matrix_core_form_vs_oracle(matrix_core_form, Hq, Hkv, splits):
+    """Same cases as the dot-product form, lengths around the 32-row stage and the 256-row page."""
+    ctxs = [0, 1, 15, 16, 17, 31, 32, 33, 255, 256, 257, 700, 2049]
+    case = make_case(len(ctxs), Hq, Hkv, 128, 256, ctxs, seed=7 + Hq * 3 + Hkv)
+    assert not dot_form(case)
+    got, want, (kc, vc), (kc_ref, vc_ref) = run_both(case, splits)
+    check_output(got, case, what=f"matrix-core Hq={Hq} Hkv={Hkv} splits={splits}")
+    assert torch.equal(vc.cpu(), vc_ref)
+    assert torch.equal(kc.cpu(), kc_ref)
+
+
+def test_matrix_core_form_edge_cases(matrix_core_form):
+    """Unallocated pages, duplicate rows, poisoned slots, small pages (multiples of the 32-row
+    stage; a 16-row page falls back to the dot-product form), no rotary + custom scale."""
+    from micro_vllm_amd.core.paged_attention import paged_attn_decode
+
+    # small pages
+    for page, ctxs in [(32, [5, 100, 333, 47]), (64, [64, 63, 65, 1000]), (16, [5, 100])]:
+        case = make_case(len(ctxs), 8, 2, 128, page, ctxs, seed=page)
+        assert dot_form(case) == (page == 16)
+        for splits in (1, 8, 0):
+            got, _, (kc, vc), (kc_ref, vc_ref) = run_both(case, splits)
+            check_output(got, case, what=f"page={page} splits={splits}")
+            assert torch.equal(kc.cpu(), kc_ref) and torch.equal(vc.cpu(), vc_ref)
+    # the block table entry of the new token is -1: write dropped, key ignored, no fault
+    case = make_case(2, 8, 2, 128, 256, [256, 100], seed=13)
+    case["bt"][0, 1] = -1
+    kc, vc = case["k_cache"].to(DEV), case["v_cache"].to(DEV)
+    got = paged_attn_decode(case["q"][:, 0].to(DEV), case["k"][:, 0].to(DEV), case["v"][:, 0].to(DEV),
+                            kc, vc, case["seqlens"].to(DEV), case["bt"].to(DEV),
+                            *[t.to(DEV) for t in (case["cos"], case["sin"])])
+    assert bool(torch.isfinite(got.float()).all())
+    assert torch.equal(kc[case["bt"][0, 0].item()].cpu(), case["k_cache"][case["bt"][0, 0].item()])
+    # duplicates
+    case = make_case(1, 8, 1, 128, 256, [300], seed=5)
+    for key in ("q", "k", "v", "bt", "seqlens"):
+        case[key] = case[key].repeat(4, *([1] * (case[key].dim() - 1)))
+    got, _, (kc, vc), (kc_ref, vc_ref) = run_both(case, 0)
+    check_output(got, case, what="duplicates")
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[3])
+    assert torch.equal(kc.cpu(), kc_ref) and torch.equal(vc.cpu(), vc_ref)
+    # no rotary, custom scale
+    case = make_case(3, 8, 2, 128, 256, [10, 200, 513], seed=8, rotary=False)
+    kc, vc = case["k_cache"].to(DEV), case["v_cache"].to(DEV)
+    got = paged_attn_decode(case["q"][:, 0].to(DEV), case["k"][:, 0].to(DEV), case["v"][:, 0].to(DEV),
+                            kc, vc, case["seqlens"].to(DEV), case["bt"].to(DEV), softmax_scale=0.2)
+    check_output(got, case, what="custom scale", scale=0.2)
+
+
+def test_matrix_core_form_merge_kernels_agree_and_poison_is_ignored(matrix_core_form):
+    from micro_vllm_amd import _native as nv
+
+    case = make_case(6, 8, 2, 128, 256, [0, 63, 64, 1000, 2049, 4096], seed=55)
+    outs = {}
+    try:
+        for mode in (1, 0, 1):
+            assert nv.lib().mv_paged_attn_tune(0, mode) == 0
+            for splits in (2, 7, 64):
+                got, _, _, _ = run_both(case, splits)
+                outs.setdefault(splits, []).append(got.clone())
+    finally:
+        nv.lib().mv_paged_attn_tune(0, 1)
+    for splits, lst in outs.items():
+        assert torch.equal(lst[0], lst[1]) and torch.equal(lst[0], lst[2]), splits
+    test_slots_that_do_not_count_may_hold_anything(None, 128, 8, 2)
