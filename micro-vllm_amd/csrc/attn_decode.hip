@@ -624,7 +624,10 @@ __global__ __launch_bounds__(256) void paged_attn_decode_mfma_kernel(AttnArgs a)
     // One stage of rows in registers: its value rows go to LDS and its key rows into the matrix
     // unit at the top of a pass, and the next stage is requested into the same registers right
     // behind them, so it has the softmax and the second product to arrive (other waves of the CU
-    // cover the rest).  Two register stages cost 64 more registers and a wave per SIMD.
+    // cover the rest).  Two register stages cost 64 more registers and a wave per SIMD, and
+    // were measured slower even where there is one workgroup per CU anyway (8 sequences x 1 kv
+    // head at ctx 8192: 16.4 against 16.2 us; one sequence x 8 kv heads at ctx 4096: 12.7 against
+    // 11.3): the second stage's requests are wasted on short splits and lengthen the prologue.
     uint4 kR[8], vR[8];
     load_k(kR, pgA, 0);
     load_v(vR, pgA, 0);
