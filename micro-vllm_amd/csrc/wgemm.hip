@@ -482,10 +482,10 @@ __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
                 for (int b = 0; b < MB; ++b) xb[i][b] = ld16(xrow[b] + kcol);
             }
         };
-        auto compute = [&](const uint4(&wb)[U][SG], const uint4(&xb)[U][MB], int c) {
+        auto compute = [&](const uint4(&wb)[U][SG], const uint4(&xb)[U][MB], int c, bool all) {
 #pragma unroll
             for (int i = 0; i < U; ++i) {
-                if (c * U + i < ntile) {  // wave-uniform
+                if (all || c * U + i < ntile) {  // wave-uniform
 #pragma unroll
                     for (int sI = 0; sI < SG; ++sI) {
                         const bf16x8_t wf = __builtin_bit_cast(bf16x8_t, wb[i][sI]);
@@ -499,12 +499,34 @@ __global__ __launch_bounds__(kGT) void wgemm_mfma_kernel(GemmArgs a) {
         };
 
         const int nchunk = (ntile + U - 1) / U;
-        if (nchunk > 0) load(wA, xA, 0);
-        for (int c = 0; c < nchunk; c += 2) {
-            if (c + 1 < nchunk) load(wB, xB, c + 1);
-            compute(wA, xA, c);
+        // Both first stages go out unconditionally (indices past the end are clamped) and the steady
+        // state has no branch around a request, so the compiler's wait counts are exact: with a
+        // request under an `if` anywhere before or inside the loop every wait covers both stages
+        // and only one is ever in flight.  The last three chunks at most are handled after it.
+        // (The fences keep the two first stages in the order the loop issues them: interleaved by
+        // the scheduler they would make the loop's first wait, and through the back edge all of
+        // them, cover both stages.)
+        __builtin_amdgcn_sched_barrier(0);
+        load(wA, xA, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        load(wB, xB, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        int c = 0;
+        for (; c + 3 < nchunk; c += 2) {
+            compute(wA, xA, c, true);
+            __builtin_amdgcn_sched_barrier(0);
+            load(wA, xA, c + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(wB, xB, c + 1, true);
+            __builtin_amdgcn_sched_barrier(0);
+            load(wB, xB, c + 3);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c < nchunk) {
+            compute(wA, xA, c, false);
             if (c + 2 < nchunk) load(wA, xA, c + 2);
-            if (c + 1 < nchunk) compute(wB, xB, c + 1);
+            if (c + 1 < nchunk) compute(wB, xB, c + 1, false);
+            if (c + 2 < nchunk) compute(wA, xA, c + 2, false);
         }
 
         // acc[s][b][j] = C[n = 16 (g SG + s) + 4q + j][m = 16b + r]
