@@ -989,7 +989,19 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint) {
     if (per_cu > 0) {
         ns = (per_cu * cus + pairs - 1) / pairs;
     } else {
-        ns = (cus + pairs - 1) / pairs;
+        // ... which, when the pairs do not divide the CUs, means: the split count whose
+        // workgroups load the fullest CU least, ceil(pairs * ns / CUs) / ns of a sequence, with a
+        // small charge per split (40 sequences x 8 kv heads: 1 split leaves 64 CUs with two whole
+        // sequences, 4 splits leave every CU with 1.25)
+        float best = 1e30f;
+        ns = 1;
+        for (int c = 1; c <= 32; ++c) {
+            const float cost = (float)((pairs * c + cus - 1) / cus) / (float)c + 0.0005f * (float)c;
+            if (cost < best) {
+                best = cost;
+                ns = c;
+            }
+        }
     }
     if (ctx_hint > 0) {
         // rows are dealt out in chunks of 64 (d = 128) or 128 (d = 64): no more splits than chunks
