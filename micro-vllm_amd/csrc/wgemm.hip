@@ -842,7 +842,7 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
             return MV_ERR_INVALID_ARG;
     }
 
-    GemmArgs a;
+    GemmArgs a = {};
     a.x = (const uint16_t*)x;
     a.ldx = ldx;
     a.w = (const uint4*)w_tiles;
