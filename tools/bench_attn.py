@@ -6,7 +6,7 @@ import micro_vllm_amd
 from micro_vllm_amd import _native as nv
 from micro_vllm_amd.core.paged_attention import paged_attn_decode, rotary_tables
 
-def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20):
+def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20, ragged_seed=None):
     dev = "cuda"
     pages = (ctx + 256) // 256 + 1
     nb = bs * pages
@@ -17,6 +17,10 @@ def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20):
     q = qkv[:, :hq * d].unflatten(1, (hq, d)); k = qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)); v = qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d))
     perm = torch.randperm(nb, device=dev).to(torch.int32).reshape(bs, pages)
     sl = torch.full((bs,), ctx, dtype=torch.int32, device=dev)
+    if ragged_seed is not None:  # lengths uniform in [256, ctx]
+        import random
+        rng = random.Random(ragged_seed)
+        sl = torch.tensor([rng.randint(min(256, ctx), ctx) for _ in range(bs)], dtype=torch.int32, device=dev)
     cos, sin = rotary_tables(d, 8192, device=dev)
     out = torch.empty(bs, hq, d, dtype=torch.bfloat16, device=dev)
     L = nv.lib()
@@ -37,8 +41,9 @@ def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20):
         for _ in range(reps): L.mv_graph_launch(h, side.cuda_stream)
         e1.record(side); side.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / (reps * layers)
-    nbytes = bs * (ctx + 1) * hkv * d * 2 * 2
-    print(f"bs={bs} hq={hq} hkv={hkv} d={d} ctx={ctx} splits={splits}: {t*1e6:8.2f} us/call  {nbytes/t/1e9:8.1f} GB/s", flush=True)
+    nbytes = int(sl.sum().item() + bs) * hkv * d * 2 * 2
+    tag = " ragged" if ragged_seed is not None else ""
+    print(f"bs={bs} hq={hq} hkv={hkv} d={d} ctx={ctx}{tag} splits={splits}: {t*1e6:8.2f} us/call  {nbytes/t/1e9:8.1f} GB/s", flush=True)
 
 if __name__ == "__main__":
     L = nv.lib()
