@@ -49,6 +49,8 @@ def parse():
                     help="steps timed one by one AFTER the timed region, for the median / p99 step")
     ap.add_argument("--ragged", action="store_true",
                     help="context lengths uniform in [256, ctx] (seed 3) instead of ctx for every row")
+    ap.add_argument("--one-split-rule", action="store_true",
+                    help="A/B switch: never replay the finer-split graph for rows of uneven length")
     ap.add_argument("--shapes", action="store_true", help="per-projection GB/s table on stderr")
     return ap.parse_args()
 
@@ -291,6 +293,8 @@ def main():
     cfg, layers, runner, mgr, ctxs = build(args, dev, world)
     bs = args.bs
     if not args.no_graph:
+        if args.one_split_rule:
+            runner.uneven_ratio = float("inf")
         runner.capture(mgr, batch_sizes=[bs])
     torch.cuda.synchronize()
     log(f"[bench] rank {rank}/{world}: {cfg.name} x{layers} layers built + captured in {time.time()-t_build:.1f}s")
@@ -398,6 +402,8 @@ def main():
             "layers": layers,
             "parallelism": f"tp{world}",
             "graph": bs in runner._graphs,   # False when capture was skipped or fell back to eager
+            # the step replayed the graph with the finer attention split (rows of uneven length)
+            "uneven_split_graph": bs in runner._graphs_uneven and runner._rows_uneven(mgr, bs),
             "sampling": "greedy argmax on device",
         },
         "step_algorithmic_GB": round(step_bytes / 1e9, 3),

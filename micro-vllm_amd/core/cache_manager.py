@@ -90,6 +90,7 @@ class KVCacheManager:
         self._sl_host = [h[:max_batch_size] for h in self._step_host]
         self._bt_host = [h[max_batch_size:].view(max_batch_size, W) for h in self._step_host]
         self._ring_events = [None] * self._ring
+        self.step_len_max = self.step_len_sum = self.step_rows = 0
         self._ring_next = 0
 
     # ------------------------------------------------------------------ allocation
@@ -167,6 +168,9 @@ class KVCacheManager:
                             f"{self.max_seq_blocks} wide (max_tokens={self.max_tokens})")
                     bt_np[i, :len(blocks)] = blocks
             sl.numpy()[:n] = context_lens
+            # what the host knows about this step's lengths: the decode runner picks its
+            # attention split count from it (uneven rows want finer work units)
+            self.step_len_max, self.step_len_sum, self.step_rows = max(context_lens), sum(context_lens), n
             upto = self._cache_seqlens_buffer.numel() + n * self.max_seq_blocks
             self._step_buf[:upto].copy_(self._step_host[slot][:upto], non_blocking=True)
             if self._on_gpu:

@@ -110,6 +110,12 @@ class ModelGraphRunner:
         self.prepare_weights()
         self._alloc_bufs()
         self._graphs: Dict[int, HipGraph] = {}
+        # second graph per batch size, captured with a finer attention split: replayed when the
+        # rows of a step differ much in length (the longest row alone then sets the pace of an
+        # unsplit launch: 32 rows uniform in [256, 4096] run 79.7 us unsplit, 70.3 us in two splits)
+        self._graphs_uneven: Dict[int, HipGraph] = {}
+        self._uneven = False
+        self.uneven_ratio = 1.25     # longest row / mean row above which the finer split is used
         self._is_graph_ready = False
         self._num_splits: Dict[int, int] = {}
 
@@ -196,8 +202,20 @@ class ModelGraphRunner:
         self._attn_ws = None
 
     # ------------------------------------------------------------------ pieces
+    def _splits_uneven(self, bs, even):
+        """Split count for rows of very different lengths.  With at least one (row, kv head) pair
+        per CU the even-length rule leaves rows whole or nearly; uneven rows are cut in two (pairs
+        up to the CU count) or four (more) so that the dispatcher can balance them."""
+        pairs = bs * self.kv_num_heads
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        if 2 * pairs <= cus:
+            return even
+        return max(even, 2 if pairs <= cus else 4)
+
     def _splits_for(self, bs, cache_manager):
         ns = self._num_splits.get(bs)
+        if self._uneven and ns is not None:
+            return self._splits_uneven(bs, ns)
         if ns is None:
             ctx = cache_manager._block_table_buffer.shape[1] * cache_manager.block_size
             ns = nv.lib().mv_paged_attn_decode_pick_splits(bs, self.kv_num_heads, self.head_size, ctx)
@@ -207,7 +225,7 @@ class ModelGraphRunner:
                 L = nv.lib()
                 need = max(L.mv_paged_attn_decode_workspace_bytes(
                     b, self.num_heads, self.head_size,
-                    max(L.mv_paged_attn_decode_pick_splits(b, self.kv_num_heads, self.head_size, ctx), 2))
+                    max(L.mv_paged_attn_decode_pick_splits(b, self.kv_num_heads, self.head_size, ctx), 4))
                     for b in range(1, self.max_bs + 1))
                 self._attn_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
         return ns
@@ -405,41 +423,69 @@ class ModelGraphRunner:
         for bs in batch_sizes:
             if bs > self.max_bs:
                 continue
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), torch.no_grad():
-                # warm-up on the buffers as they are: every kernel guards its page lookups, so
-                # stale or -1 entries are skipped, never dereferenced
-                for _ in range(warmup):
-                    self.decode(self._input_ids[:bs], bs, cache_manager)
-                side.synchronize()
-                if use_torch_graph:
-                    try:
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, stream=side):
-                            self.decode(self._input_ids[:bs], bs, cache_manager)
-                        self._graphs[bs] = g
-                    except Exception as e:  # collective not capturable here: run this bs eagerly
-                        logger.warning("graph capture with collectives failed for bs=%d (%r); "
-                                       "decode will launch eagerly", bs, e)
-                        torch.cuda.synchronize()
-                else:
-                    import ctypes
-                    nv.check("mv_graph_begin_capture", nv.lib().mv_graph_begin_capture(side.cuda_stream))
-                    try:
-                        self.decode(self._input_ids[:bs], bs, cache_manager)
-                    finally:
-                        handle = ctypes.c_void_p()
-                        rc = nv.lib().mv_graph_end_capture(side.cuda_stream, ctypes.byref(handle))
-                    nv.check("mv_graph_end_capture", rc)
-                    self._graphs[bs] = HipGraph(handle)
-            torch.cuda.current_stream().wait_stream(side)
+            even = self._splits_for(bs, cache_manager)
+            for uneven in (False, True):
+                if uneven and self._splits_uneven(bs, even) == even:
+                    continue  # same launch either way
+                self._uneven = uneven
+                try:
+                    g = self._capture_one(bs, cache_manager, warmup, use_torch_graph)
+                finally:
+                    self._uneven = False
+                if g is not None:
+                    (self._graphs_uneven if uneven else self._graphs)[bs] = g
             logger.info("captured decode graph for batch size %d", bs)
         self._is_graph_ready = True
 
+    def _capture_one(self, bs, cache_manager, warmup, use_torch_graph):
+        """One decode step for `bs` rows as a replayable graph (None when it cannot be captured)."""
+        g = None
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            # warm-up on the buffers as they are: every kernel guards its page lookups, so
+            # stale or -1 entries are skipped, never dereferenced
+            for _ in range(warmup):
+                self.decode(self._input_ids[:bs], bs, cache_manager)
+            side.synchronize()
+            if use_torch_graph:
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        self.decode(self._input_ids[:bs], bs, cache_manager)
+                except Exception as e:  # collective not capturable here: run this bs eagerly
+                    logger.warning("graph capture with collectives failed for bs=%d (%r); "
+                                   "decode will launch eagerly", bs, e)
+                    torch.cuda.synchronize()
+                    g = None
+            else:
+                import ctypes
+                nv.check("mv_graph_begin_capture", nv.lib().mv_graph_begin_capture(side.cuda_stream))
+                try:
+                    self.decode(self._input_ids[:bs], bs, cache_manager)
+                finally:
+                    handle = ctypes.c_void_p()
+                    rc = nv.lib().mv_graph_end_capture(side.cuda_stream, ctypes.byref(handle))
+                nv.check("mv_graph_end_capture", rc)
+                g = HipGraph(handle)
+        torch.cuda.current_stream().wait_stream(side)
+        return g
+
+    def _rows_uneven(self, cache_manager, batch_size) -> bool:
+        """Whether the lengths the cache manager last wrote for this batch differ enough for the
+        finer attention split (host-side knowledge only: nothing is read back from the device)."""
+        n = getattr(cache_manager, "step_rows", 0)
+        if n != batch_size or n < 2:
+            return False
+        return cache_manager.step_len_max * n > self.uneven_ratio * cache_manager.step_len_sum
+
     def forward(self, input_ids: torch.Tensor, cache_manager, batch_size: int) -> torch.Tensor:
         self._input_ids[:batch_size] = input_ids
-        g = self._graphs.get(batch_size)
+        g = None
+        if self._graphs_uneven and self._rows_uneven(cache_manager, batch_size):
+            g = self._graphs_uneven.get(batch_size)
+        if g is None:
+            g = self._graphs.get(batch_size)
         if g is None:
             return self.decode(self._input_ids[:batch_size], batch_size, cache_manager)
         g.replay()

@@ -180,6 +180,37 @@ def test_graph_replay_equals_eager_and_oracle(mv, bs):
         pos = [p + 1 for p in pos]
 
 
+def test_uneven_rows_replay_the_finer_split_graph(mv):
+    """Rows of very different lengths replay the second graph of their batch size (finer
+    attention split), rows of similar lengths the first; both agree with the oracle.  The rule
+    that decides when a finer split exists looks at the CU count, which no test-sized batch
+    reaches, so the test supplies its own."""
+    cfg, runner, mgr, ref, ref_cache = build(mv, "tiny-gqa", n_blocks=40)
+    runner._splits_uneven = lambda bs, even: even * 2
+    seq_lens = [3, 500, 9, 31]
+    prefill_random_kv(mgr, ref_cache, seq_lens, seed=5)
+    runner.capture(mgr, batch_sizes=[4])
+    assert 4 in runner._graphs and 4 in runner._graphs_uneven
+    replayed = []
+    for graphs in (runner._graphs, runner._graphs_uneven):
+        g, inner = graphs[4], graphs[4].replay
+        g.replay = (lambda inner=inner, graphs=graphs: (replayed.append(graphs), inner())[1])
+    gen = torch.Generator().manual_seed(4)
+    pos = [L + 1 for L in seq_lens]
+    for step in range(3):
+        ids = torch.randint(0, cfg.vocab_size, (4,), generator=gen)
+        got, want = step_both(cfg, runner, mgr, ref, ref_cache, [0, 1, 2, 3], pos, ids, use_graph=True)
+        assert replayed[-1] is runner._graphs_uneven
+        assert_close_bf16(got, want, atol=FREE_RUN_ATOL(want), rtol=2 ** -7, what=f"uneven step {step}")
+        assert (got.argmax(-1) == want.argmax(-1)).all()
+        pos = [p + 1 for p in pos]
+    # the same sequence in every row: equal lengths, first graph
+    ids = torch.full((4,), 7)
+    got, want = step_both(cfg, runner, mgr, ref, ref_cache, [1, 1, 1, 1], [pos[1]] * 4, ids, use_graph=True)
+    assert replayed[-1] is runner._graphs
+    assert_close_bf16(got, want, atol=FREE_RUN_ATOL(want), rtol=2 ** -7, what="even step")
+
+
 def test_duplicate_padded_batch(mv):
     """bs=4 graph fed 3 live sequences + 1 duplicate, as core/scheduler.py:88-92 pads."""
     cfg, runner, mgr, ref, ref_cache = build(mv, "tiny-gqa")
