@@ -1,8 +1,9 @@
 """Engine glue around the two runners: request intake, one scheduler decision per step, prefill /
 decode drivers, token bookkeeping.  Mirrors the reference's InferenceEngine
-(core/engine.py:35-309) method for method; the model and tokenizer are handed in as objects
-(checkpoint loading is a separate concern), and the KV pool geometry is a constructor argument
-instead of the reference's fixed 81 blocks / 4-column block table.
+(core/engine.py:35-309) method for method; the model comes from a safetensors checkpoint
+directory (`model_path`, core/model_loader.py) or is handed in as an object with its tokenizer,
+and the KV pool geometry is a constructor argument instead of the reference's fixed 81 blocks /
+4-column block table.
 """
 import logging
 import time
@@ -38,15 +39,23 @@ class InferenceEngine:
     def __init__(self, model_path: Optional[str] = None, max_batch_size: int = 40,
                  max_prefill_tokens: int = 2048, *, model=None, tokenizer=None,
                  n_blocks: Optional[int] = None, max_tokens: int = 1024,
-                 graph_batch_sizes: Optional[List[int]] = None, prefill_timeout: float = 0.02):
+                 graph_batch_sizes: Optional[List[int]] = None, prefill_timeout: float = 0.02,
+                 exact_rope: bool = False, trust_remote_code: bool = False):
         """`max_tokens` is the longest sequence a block-table row can describe (the reference's
-        KVCacheManager default, 1024, gives four columns - pass more for long contexts)."""
+        KVCacheManager default, 1024, gives four columns - pass more for long contexts).
+        `exact_rope` builds the rotary tables from fp32 positions; the default keeps the
+        reference's bf16 positions (core/paged_attention.py:50-52), which merge neighbouring
+        positions above 256 - with a trained checkpoint and long contexts pass True."""
         setup()
         self.rank = get_rank()
         if model is None:
-            raise NotImplementedError(
-                "checkpoint loading is not part of this path: pass model= and tokenizer= "
-                f"(got model_path={model_path!r})")
+            if model_path is None:
+                raise ValueError("pass model_path= (a safetensors checkpoint directory) or model=")
+            from .model_loader import load_model
+            logger.info("Loading model %s on rank %d", model_path, self.rank)
+            model, loaded_tok = load_model(model_path, tokenizer=tokenizer is None,
+                                           trust_remote_code=trust_remote_code)
+            tokenizer = tokenizer if tokenizer is not None else loaded_tok
         assert torch.cuda.is_available(), "the HIP library is the only compute path"
         torch.cuda.set_device(self.rank % max(1, torch.cuda.device_count()))
         self.device, self.dtype = "cuda", torch.bfloat16
@@ -74,7 +83,7 @@ class InferenceEngine:
                            head_size=self.head_size, kv_num_heads=self.kv_num_heads,
                            hidden_dim=cfg.hidden_size, intermediate_size=self.intermediate_size,
                            device=self.device, max_batch_size=max_batch_size, dtype=self.dtype,
-                           max_blocks=max_blocks)
+                           max_blocks=max_blocks, exact_rope=exact_rope)
         self.graph_runner = ModelGraphRunner(**runner_args)
         self.prefill_runner = ModelPrefillRunner(**runner_args)
         self.scheduler = Scheduler(max_batch_size, max_prefill_tokens, tokenizer, prefill_timeout)

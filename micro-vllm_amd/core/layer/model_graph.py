@@ -106,7 +106,8 @@ class ModelGraphRunner:
         self.release_source_weights = release_source_weights
 
         self.attention = PagedAttention(num_heads, head_size, kv_num_heads, device, max_batch_size,
-                                        max_blocks=max_blocks, exact_positions=exact_rope)
+                                        max_blocks=max_blocks, exact_positions=exact_rope,
+                                        rope_base=float(getattr(model.config, "rope_theta", 10000.0)))
         self.prepare_weights()
         self._alloc_bufs()
         self._graphs: Dict[int, HipGraph] = {}

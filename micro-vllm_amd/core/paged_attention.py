@@ -64,7 +64,7 @@ class PagedAttention(nn.Module):
 
     def __init__(self, num_heads: int, head_size: int, kv_num_heads: int, device: str = "auto",
                  max_batch_size=16, max_blocks=32, max_position=4096, max_tokens=8192,
-                 block_size=256, exact_positions: bool = False):
+                 block_size=256, exact_positions: bool = False, rope_base: float = 10000.0):
         super().__init__()
         self.block_size = block_size
         self.max_tokens = max_tokens
@@ -79,7 +79,7 @@ class PagedAttention(nn.Module):
         self.max_batch_size = max_batch_size
         self.max_blocks = max_blocks
         max_kv_capacity = max_blocks * 256
-        cos, sin = rotary_tables(head_size, max_kv_capacity, 10000.0, self.device, exact_positions)
+        cos, sin = rotary_tables(head_size, max_kv_capacity, rope_base, self.device, exact_positions)
         self._cos_pool = cos.to(torch.bfloat16).contiguous()
         self._sin_pool = sin.to(torch.bfloat16).contiguous()
 

@@ -31,6 +31,7 @@ class SyntheticConfig:
     ffn_hidden_size: int  # I
     layer_norm_epsilon: float = 1e-6
     max_position_embeddings: int = 8192
+    rope_theta: float = 10000.0   # base of the rotary frequencies
 
     @property
     def intermediate_size(self) -> int:  # Qwen-1 meaning: gate + up

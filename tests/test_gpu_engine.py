@@ -191,3 +191,36 @@ def test_engine_soak_many_ragged_requests(mv):
         assert {n for k, n in sizes if k == "decode"} >= {1, 2, 4, 8} or wave > 0
         eng.scheduler.get_finished_results()
         eng.scheduler.running_sequences.clear()
+
+
+@pytest.mark.parametrize("scheme,shape,bias", [("llama", "tiny-d128", False), ("qwen", "tiny-mha", True)])
+def test_engine_from_a_checkpoint_directory_equals_engine_from_the_model_object(mv, tmp_path, scheme, shape, bias):
+    """`InferenceEngine(model_path=...)` (core/engine.py:45-47, core/model_loader.py:6): the
+    safetensors directory is read parameter by parameter and must give the very same greedy
+    continuations as the model object it was written from; the rotary base of the checkpoint's
+    config reaches the rotary tables."""
+    import dataclasses
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from ckpt_util import write_checkpoint
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.core.paged_attention import rotary_tables
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    theta = 500000.0 if scheme == "llama" else 10000.0
+    cfg = dataclasses.replace(SHAPES[shape], rope_theta=theta)
+    tok = Tok(cfg.vocab_size)
+    src = build_synthetic_model(cfg, "cpu", seed=11, qkv_bias=bias, norm_jitter=0.1)
+    path = write_checkpoint(src, str(tmp_path / "ckpt"), scheme, shards=2)
+    prompts = ["a" * 12, "bc" * 9, "hello world, this is a longer prompt " * 2]
+    kw = dict(tokenizer=tok, max_batch_size=4, n_blocks=24, max_tokens=1024, graph_batch_sizes=[1, 2, 4],
+              prefill_timeout=0.0)
+    a = InferenceEngine(model_path=path, **kw)
+    cos, sin = rotary_tables(cfg.head_dim, a.graph_runner.attention._cos_pool.shape[0], theta, DEV)
+    assert torch.equal(a.graph_runner.attention._cos_pool, cos.to(torch.bfloat16))
+    assert torch.equal(a.graph_runner.attention._sin_pool, sin.to(torch.bfloat16))
+    got = a.generate(prompts, max_tokens=6, temperature=0.0)
+    b = InferenceEngine(model=src.to(DEV), **kw)
+    want = b.generate(prompts, max_tokens=6, temperature=0.0)
+    assert got == want and len(got) == len(prompts)
+    assert all(len(v.split()) >= 1 for v in got.values())
