@@ -57,7 +57,8 @@ class InferenceEngine:
                                            trust_remote_code=trust_remote_code)
             tokenizer = tokenizer if tokenizer is not None else loaded_tok
         assert torch.cuda.is_available(), "the HIP library is the only compute path"
-        torch.cuda.set_device(self.rank % max(1, torch.cuda.device_count()))
+        self.device_index = self.rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(self.device_index)   # per thread: a serving thread sets it again
         self.device, self.dtype = "cuda", torch.bfloat16
         self.model, self.tokenizer = model, tokenizer
         self.config = model.config

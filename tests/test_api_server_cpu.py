@@ -1,0 +1,152 @@
+"""HTTP front end and load generator on the CPU (reference: api_server.py:96-184, benchmark.py):
+the real Scheduler / Sequence / update_sequences bookkeeping, with the device step replaced by a
+rule (next token = last token + 1), so every response is predictable."""
+import asyncio
+import json
+import threading
+
+import pytest
+
+import micro_vllm_amd  # noqa: F401
+from micro_vllm_amd.api_server import EngineLoop, create_app
+from micro_vllm_amd.core.engine import InferenceEngine
+from micro_vllm_amd.core.scheduler import Scheduler
+
+VOCAB = 1000
+
+
+class Tok:
+    eos_token_id = 2
+
+    def encode(self, prompt, add_special_tokens=True):
+        return [5 + (ord(c) * 7) % (VOCAB - 5) for c in prompt]
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(i) for i in ids)
+
+
+class Pages:
+    def __init__(self):
+        self.freed = []
+
+    def free(self, sid):
+        self.freed.append(sid)
+
+
+class RuleEngine(InferenceEngine):
+    """InferenceEngine's request intake and token bookkeeping over a step that needs no device."""
+
+    def __init__(self, fail_on=None):
+        self.tokenizer = Tok()
+        self.scheduler = Scheduler(8, 2048, self.tokenizer, prefill_timeout=0.0)
+        self.scheduler.batch_sizes = [1, 2, 4, 8]
+        self.stream_callbacks = {}
+        self.cache_manager = Pages()
+        self.eos_token_id = self.tokenizer.eos_token_id
+        self.device = "rule"
+        self.fail_on = fail_on
+        self.kinds = []
+
+    def step(self, ctx):
+        self.kinds.append((ctx.batch_type, len(ctx.sequences)))
+        if self.fail_on and any(self.fail_on in s.prompt for s in ctx.sequences):
+            raise RuntimeError("OOM")
+        for s in ctx.sequences:
+            s._next_token = 5 + (s.full_ids[-1] + 1 - 5) % (VOCAB - 5)
+        return True
+
+
+def expected(prompt, n):
+    ids = Tok().encode(prompt)
+    out = []
+    for _ in range(n):
+        out.append(5 + ((out[-1] if out else ids[-1]) + 1 - 5) % (VOCAB - 5))
+    return ids, out
+
+
+@pytest.fixture
+def client():
+    from starlette.testclient import TestClient
+    eng = RuleEngine()
+    loop = EngineLoop(eng)
+    loop.start()
+    with TestClient(create_app(loop, "rule-model")) as c:
+        c.engine, c.loop = eng, loop
+        yield c
+    loop.stop()
+
+
+def test_health_generate_and_batch(client):
+    h = client.get("/health").json()
+    assert h == {"status": "healthy", "model": "rule-model", "device": "rule",
+                 "running_sequences": 0, "waiting_sequences": 0}
+    r = client.post("/generate", json={"prompt": "hello", "max_tokens": 5}).json()
+    ids, out = expected("hello", 5)
+    assert r["text"] == Tok().decode(ids + out) and r["tokens"] == 5 and r["time_ms"] > 0
+    prompts = ["ab", "a much longer prompt than the others " * 3, "xyz"]
+    r = client.post("/batch_generate", json={"prompts": prompts, "max_tokens": 4}).json()
+    assert [x["text"] for x in r["results"]] == [Tok().decode(sum(expected(p, 4), [])) for p in prompts]
+    assert len(client.engine.cache_manager.freed) == 4            # every sequence returned its pages
+    assert not client.loop._requests and not client.engine.stream_callbacks
+    assert not client.engine.scheduler.finished_sequences       # drained by the loop, no growth
+    assert client.engine.kinds[0][0] == "prefill" and any(k == "decode" for k, _ in client.engine.kinds)
+
+
+def test_stream_emits_one_event_per_token(client):
+    with client.stream("POST", "/generate_stream",
+                       json={"prompt": "stream me", "max_tokens": 6, "stream": True}) as resp:
+        assert resp.headers["content-type"].startswith("text/event-stream")
+        events = [json.loads(l[5:]) for l in resp.iter_lines() if l.startswith("data:")]
+    _, out = expected("stream me", 6)
+    assert [e["token"] for e in events] == out
+    assert events[-1]["full_text"] == "".join(str(t) for t in out)
+    assert all(e["finished"] == (e["token"] == 2) for e in events)
+    # stream=False falls back to the plain response, as the reference does
+    r = client.post("/generate_stream", json={"prompt": "x", "max_tokens": 2}).json()
+    assert r["tokens"] == 2
+
+
+def test_a_failing_step_fails_its_requests_and_the_loop_goes_on():
+    from starlette.testclient import TestClient
+    eng = RuleEngine(fail_on="boom")
+    loop = EngineLoop(eng)
+    loop.start()
+    try:
+        with TestClient(create_app(loop)) as c:
+            assert c.post("/generate", json={"prompt": "boom", "max_tokens": 3}).status_code == 500
+            assert c.post("/generate", json={"prompt": "fine", "max_tokens": 3}).json()["tokens"] == 3
+            assert c.get("/health").json()["running_sequences"] == 0
+    finally:
+        loop.stop()
+
+
+def test_load_generator_against_a_live_server():
+    """The load generator over real sockets: uvicorn in a thread, aiohttp client."""
+    import socket
+    import time
+    import uvicorn
+    from micro_vllm_amd import benchmark
+
+    eng = RuleEngine()
+    loop = EngineLoop(eng)
+    loop.start()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    server = uvicorn.Server(uvicorn.Config(create_app(loop), log_level="warning"))
+    th = threading.Thread(target=lambda: server.run(sockets=[sock]), daemon=True)
+    th.start()
+    try:
+        for _ in range(200):
+            if server.started:
+                break
+            time.sleep(0.05)
+        assert server.started
+        out = asyncio.run(benchmark.run(f"http://127.0.0.1:{port}", 6, 7))
+        assert out["requests"] == 6 and out["tokens"] == 6 * 7
+        assert out["tokens_per_s"] > 0 and out["ttft_s_median"] is not None
+        assert out["latency_s_p99"] >= out["latency_s_median"] >= out["ttft_s_median"]
+    finally:
+        server.should_exit = True
+        th.join(timeout=10)
+        loop.stop()

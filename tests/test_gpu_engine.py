@@ -224,3 +224,42 @@ def test_engine_from_a_checkpoint_directory_equals_engine_from_the_model_object(
     want = b.generate(prompts, max_tokens=6, temperature=0.0)
     assert got == want and len(got) == len(prompts)
     assert all(len(v.split()) >= 1 for v in got.values())
+
+
+def test_http_front_end_over_the_real_engine(mv):
+    """api_server.py:96-184 over the device path: the engine runs on the server's own thread;
+    greedy /generate, /batch_generate and the event stream give the tokens `engine.generate` gives."""
+    import json
+    from starlette.testclient import TestClient
+    from micro_vllm_amd.api_server import EngineLoop, create_app
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES["tiny-gqa"]
+    tok = Tok(cfg.vocab_size)
+    kw = dict(tokenizer=tok, max_batch_size=4, n_blocks=24, max_tokens=1024, graph_batch_sizes=[1, 2, 4],
+              prefill_timeout=0.0)
+    prompts = ["a" * 12, "bc" * 9, "hello world, this is a longer prompt " * 2]
+    want = InferenceEngine(model=build_synthetic_model(cfg, "cpu", seed=3, norm_jitter=0.1).to(DEV), **kw) \
+        .generate(prompts, max_tokens=6, temperature=0.0)
+    eng = InferenceEngine(model=build_synthetic_model(cfg, "cpu", seed=3, norm_jitter=0.1).to(DEV), **kw)
+    loop = EngineLoop(eng)
+    loop.start()
+    try:
+        with TestClient(create_app(loop)) as c:
+            assert c.get("/health").json()["device"] == "cuda"
+            r = c.post("/generate", json={"prompt": prompts[0], "max_tokens": 6, "temperature": 0.0}).json()
+            assert r["text"] == want[prompts[0]] and 1 <= r["tokens"] <= 6
+            r = c.post("/batch_generate", json={"prompts": prompts, "max_tokens": 6, "temperature": 0.0}).json()
+            assert [x["text"] for x in r["results"]] == [want[p] for p in prompts]
+            with c.stream("POST", "/generate_stream", json={"prompt": prompts[1], "max_tokens": 6,
+                                                            "temperature": 0.0, "stream": True}) as resp:
+                events = [json.loads(l[5:]) for l in resp.iter_lines() if l.startswith("data:")]
+            streamed = [e["token"] for e in events]
+            assert tok.decode(tok.encode(prompts[1]) + streamed) == want[prompts[1]]
+            # sampled requests go through the in-graph pick and come back with valid ids
+            r = c.post("/generate", json={"prompt": "zz", "max_tokens": 5, "temperature": 0.8}).json()
+            assert 1 <= r["tokens"] <= 5
+    finally:
+        loop.stop()
+    assert eng.cache_manager.stats["free"] == 24
