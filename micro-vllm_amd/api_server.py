@@ -63,7 +63,14 @@ class EngineLoop:
                 self.engine.register_stream_callback(seq_id, on_token)
         return seq_id
 
-    def start(self):
+    def start(self, switch_interval: Optional[float] = 2e-4):
+        """`switch_interval`: the interpreter hands the GIL from a busy thread to a waiting one only
+        every 5 ms by default - longer than a decode step, so the engine thread coming back from
+        its wait on the device would sit behind the event loop's response writing.  A short
+        interval keeps the device fed; None leaves the setting alone."""
+        if switch_interval is not None:
+            import sys
+            sys.setswitchinterval(switch_interval)
         self._running = True
         self._thread = threading.Thread(target=self.run, name="engine-loop", daemon=True)
         self._thread.start()

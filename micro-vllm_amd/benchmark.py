@@ -24,11 +24,18 @@ FORMS = ["Explain {} to a new engineer.", "Write a short essay about {}.", "Comp
          "Give a step-by-step study plan for {}.", "Write example code for {}."]
 
 
-def make_requests(n: int, max_tokens: int, seed: int = 0):
+def make_requests(n: int, max_tokens: int, seed: int = 0, prompt_chars: int = 0):
+    """`prompt_chars` > 0 pads / cuts every prompt to that many characters (prompts of a known
+    length for a server whose tokenizer maps characters to tokens)."""
     rng = random.Random(seed)
-    return [{"prompt": rng.choice(FORMS).format(rng.choice(TOPICS)) + f" (request {i})",
+    reqs = [{"prompt": rng.choice(FORMS).format(rng.choice(TOPICS)) + f" (request {i})",
              "max_tokens": max_tokens, "temperature": rng.choice([0.5, 0.6, 0.7, 0.8, 0.9]),
              "top_p": 0.9, "stream": True} for i in range(n)]
+    if prompt_chars > 0:
+        for i, r in enumerate(reqs):
+            fill = "".join(chr(33 + (i * 31 + j * 7) % 90) for j in range(prompt_chars))
+            r["prompt"] = (r["prompt"] + " " + fill)[:prompt_chars]
+    return reqs
 
 
 async def send_request(session, url: str, data: dict):
@@ -66,13 +73,13 @@ def summarize(results, wall: float) -> dict:
             "latency_s_median": pct(lat, 0.5), "latency_s_p99": pct(lat, 0.99)}
 
 
-async def run(url: str, n: int, max_tokens: int, seed: int = 0, session=None) -> dict:
+async def run(url: str, n: int, max_tokens: int, seed: int = 0, session=None, prompt_chars: int = 0) -> dict:
     import aiohttp
     own = session is None
     session = session or aiohttp.ClientSession(timeout=aiohttp.ClientTimeout(total=None))
     try:
         t0 = time.time()
-        results = await asyncio.gather(*[send_request(session, url, d) for d in make_requests(n, max_tokens, seed)])
+        results = await asyncio.gather(*[send_request(session, url, d) for d in make_requests(n, max_tokens, seed, prompt_chars)])
         return summarize(results, time.time() - t0)
     finally:
         if own:
@@ -85,8 +92,9 @@ def main(argv=None):
     ap.add_argument("--url", default="http://127.0.0.1:8000")
     ap.add_argument("--max-tokens", type=int, default=500)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--prompt-chars", type=int, default=0, help="pad / cut every prompt to this many characters")
     args = ap.parse_args(argv)
-    print(json.dumps(asyncio.run(run(args.url, args.batch_size, args.max_tokens, args.seed))))
+    print(json.dumps(asyncio.run(run(args.url, args.batch_size, args.max_tokens, args.seed, prompt_chars=args.prompt_chars))))
 
 
 if __name__ == "__main__":
