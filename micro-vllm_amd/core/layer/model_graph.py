@@ -116,7 +116,10 @@ class ModelGraphRunner:
         # unsplit launch: 32 rows uniform in [256, 4096] run 79.7 us unsplit, 70.3 us in two splits)
         self._graphs_uneven: Dict[int, HipGraph] = {}
         self._uneven = False
-        self.uneven_ratio = 1.25     # longest row / mean row above which the finer split is used
+        # longest row / mean row above which the finer split is used; None = by measurement
+        # (tools/sweep_attn_uneven_ratio.py, rows uniform in [lo, 4096]: 32 rows break even at 1.5
+        # and gain 12 % at 1.9, below 1.5 two splits LOSE 6-7 %; 64 rows break even near 1.27)
+        self.uneven_ratio = None
         self._is_graph_ready = False
         self._num_splits: Dict[int, int] = {}
 
@@ -478,7 +481,11 @@ class ModelGraphRunner:
         n = getattr(cache_manager, "step_rows", 0)
         if n != batch_size or n < 2:
             return False
-        return cache_manager.step_len_max * n > self.uneven_ratio * cache_manager.step_len_sum
+        ratio = self.uneven_ratio
+        if ratio is None:
+            cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+            ratio = 1.5 if batch_size * self.kv_num_heads <= cus else 1.3
+        return cache_manager.step_len_max * n > ratio * cache_manager.step_len_sum
 
     def forward(self, input_ids: torch.Tensor, cache_manager, batch_size: int) -> torch.Tensor:
         self._input_ids[:batch_size] = input_ids

@@ -6,7 +6,7 @@ import micro_vllm_amd
 from micro_vllm_amd import _native as nv
 from micro_vllm_amd.core.paged_attention import paged_attn_decode, rotary_tables
 
-def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20, ragged_seed=None):
+def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20, ragged_seed=None, ragged_lo=256):
     dev = "cuda"
     pages = (ctx + 256) // 256 + 1
     nb = bs * pages
@@ -17,10 +17,10 @@ def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20, ragged_seed=None):
     q = qkv[:, :hq * d].unflatten(1, (hq, d)); k = qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)); v = qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d))
     perm = torch.randperm(nb, device=dev).to(torch.int32).reshape(bs, pages)
     sl = torch.full((bs,), ctx, dtype=torch.int32, device=dev)
-    if ragged_seed is not None:  # lengths uniform in [256, ctx]
+    if ragged_seed is not None:  # lengths uniform in [ragged_lo, ctx]
         import random
         rng = random.Random(ragged_seed)
-        sl = torch.tensor([rng.randint(min(256, ctx), ctx) for _ in range(bs)], dtype=torch.int32, device=dev)
+        sl = torch.tensor([rng.randint(min(ragged_lo, ctx), ctx) for _ in range(bs)], dtype=torch.int32, device=dev)
     cos, sin = rotary_tables(d, 8192, device=dev)
     out = torch.empty(bs, hq, d, dtype=torch.bfloat16, device=dev)
     L = nv.lib()
@@ -42,7 +42,9 @@ def run(bs, hq, hkv, d, ctx, layers=32, splits=0, reps=20, ragged_seed=None):
         e1.record(side); side.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / (reps * layers)
     nbytes = int(sl.sum().item() + bs) * hkv * d * 2 * 2
-    tag = " ragged" if ragged_seed is not None else ""
+    tag = ""
+    if ragged_seed is not None:
+        tag = f" ragged[{ragged_lo},{ctx}] longest/mean {sl.max().item() * bs / sl.sum().item():.2f}"
     print(f"bs={bs} hq={hq} hkv={hkv} d={d} ctx={ctx}{tag} splits={splits}: {t*1e6:8.2f} us/call  {nbytes/t/1e9:8.1f} GB/s", flush=True)
 
 if __name__ == "__main__":
