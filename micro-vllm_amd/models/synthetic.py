@@ -60,6 +60,10 @@ SHAPES = {
     # divided by 8; hidden size, vocabulary and layer count unchanged): per-GPU kernel work of that
     # configuration without the all-reduces
     "llama3-70b-tp8shard": SyntheticConfig("llama3-70b-tp8shard", 128256, 8192, 80, 8, 1, 128, 3584, 1e-5),
+    # one rank's slice of Llama-3-8B under 2-, 4- and 8-way tensor parallelism (same convention)
+    "llama3-8b-tp2shard": SyntheticConfig("llama3-8b-tp2shard", 128256, 4096, 32, 16, 4, 128, 7168, 1e-5),
+    "llama3-8b-tp4shard": SyntheticConfig("llama3-8b-tp4shard", 128256, 4096, 32, 8, 2, 128, 3584, 1e-5),
+    "llama3-8b-tp8shard": SyntheticConfig("llama3-8b-tp8shard", 128256, 4096, 32, 4, 1, 128, 1792, 1e-5),
     # small shapes for tests (all kernel paths, seconds on a CPU)
     "tiny-gqa": SyntheticConfig("tiny-gqa", 512, 256, 2, 8, 2, 64, 512, 1e-6, 2048),
     "tiny-mha": SyntheticConfig("tiny-mha", 512, 256, 2, 4, 4, 64, 384, 1e-6, 2048),
