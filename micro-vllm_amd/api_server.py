@@ -110,6 +110,9 @@ class EngineLoop:
                 eng.scheduler.get_finished_results()      # drained here: completions go out below
             self.steps += 1
             self._report(ctx.sequences)
+        # tell the other ranks that no further step will come (the reference's followers have no
+        # way out of their loop, api_server.py:79-90)
+        BatchInferenceContext(0, "idle").broadcast()
 
     def _report(self, sequences, error=None):
         seen = set()
@@ -138,6 +141,8 @@ class EngineLoop:
         self._running = True
         while self._running:
             ctx = BatchInferenceContext.receive(eng.tokenizer)
+            if ctx.batch_type == "idle":
+                break                       # rank 0 has stopped serving
             if ctx.batch_type == "waiting" or ctx.batch_size == 0:
                 continue
             eng.step(ctx)

@@ -150,3 +150,62 @@ def test_load_generator_against_a_live_server():
         server.should_exit = True
         th.join(timeout=10)
         loop.stop()
+
+
+def _rank_worker(rank, world, port, out_q):
+    import os, sys, time
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVLLM_DIST_BACKEND="gloo")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch
+    torch.set_num_threads(1)
+    from micro_vllm_amd.core import parallel_config as pc
+    pc.setup()
+    eng = RuleEngine()
+    loop = EngineLoop(eng)
+    if rank == 0:
+        done = {}
+        loop.start()
+        prompts = ["ab", "a much longer prompt than the others " * 3, "xyz", "q"]
+        for p in prompts:
+            loop.submit(p, 5, 0.0, 0.9, on_done=lambda seq, err, p=p: done.__setitem__(p, list(seq.output_ids)))
+        for _ in range(2000):
+            if len(done) == len(prompts):
+                break
+            time.sleep(0.005)
+        loop.stop()
+        out_q.put((rank, {p: done.get(p) for p in prompts}, sorted(eng.cache_manager.freed), eng.kinds))
+    else:
+        loop.run_follower()                 # returns when rank 0 stops
+        out_q.put((rank, None, sorted(eng.cache_manager.freed), eng.kinds))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_run_the_same_steps_and_retire_the_same_sequences():
+    """world_size 2 over gloo: rank 0's loop broadcasts every step before and after it, the
+    follower runs the same batches (api_server.py:61-90), applies the same tokens, returns the
+    same pages, and leaves its loop when rank 0 stops."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        rank, outs, freed, kinds = q.get(timeout=120)
+        got[rank] = (outs, freed, kinds)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    outs, freed0, kinds0 = got[0]
+    for prompt, ids in outs.items():
+        assert ids == expected(prompt, 5)[1], prompt
+    assert got[1][1] == freed0 and len(freed0) == 4
+    assert got[1][2] == kinds0 and kinds0[0][0] == "prefill"
