@@ -1,7 +1,8 @@
 """The whole serving stack on one GPU, measured the way the reference measures itself (load
 generator -> HTTP -> scheduler -> prefill / graph decode -> event stream): a Llama-3-8B-shaped
 random-weight engine behind uvicorn on a loopback socket, N concurrent streaming requests.
-   python tools/bench_server.py [N=32] [PROMPT=512] [GEN=128]
+   python tools/bench_server.py [N=32] [PROMPT=512] [GEN=128] [MAX_BATCH=N]
+MAX_BATCH below N makes requests queue behind the running batch (continuous batching).
 Sampled decoding (the load generator's temperatures), one token per character of the prompt."""
 import os, socket, subprocess, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,6 +13,7 @@ from micro_vllm_amd.core.engine import InferenceEngine
 from micro_vllm_amd.models import SHAPES, build_synthetic_model
 
 n, plen, gen = (int(a) for a in (sys.argv[1:4] + ["32", "512", "128"][len(sys.argv[1:4]):]))
+max_bs = int(sys.argv[4]) if len(sys.argv) > 4 else max(n, 1)
 
 
 class Tok:
@@ -30,9 +32,9 @@ class Tok:
 cfg = SHAPES["llama3-8b"]
 model = build_synthetic_model(cfg, "cuda", seed=1234)
 blocks = n * ((plen + gen + 255) // 256 + 1) + 4
-eng = InferenceEngine(model=model, tokenizer=Tok(cfg.vocab_size), max_batch_size=max(n, 1),
+eng = InferenceEngine(model=model, tokenizer=Tok(cfg.vocab_size), max_batch_size=max_bs,
                       max_prefill_tokens=max(2048, plen), n_blocks=blocks, max_tokens=plen + gen + 256,
-                      graph_batch_sizes=[b for b in (1, 2, 4, 8, 16, 32, 40) if b <= n] or [n])
+                      graph_batch_sizes=[b for b in (1, 2, 4, 8, 16, 32, 40) if b <= max_bs] or [max_bs])
 loop = EngineLoop(eng)
 loop.start()
 sock = socket.socket()
