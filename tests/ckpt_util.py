@@ -70,3 +70,19 @@ def write_checkpoint(model, path, scheme, shards=1, tie_head=False):
         with open(os.path.join(path, "model.safetensors.index.json"), "w") as f:
             json.dump({"metadata": {}, "weight_map": weight_map}, f)
     return path
+
+
+def write_byte_tokenizer(path):
+    """A byte-level tokenizer (256 byte tokens + one end-of-text token, no merges) saved the way
+    `AutoTokenizer.from_pretrained(path, local_files_only=True)` reads it: any text round-trips, every
+    id is below 257, nothing is downloaded."""
+    from tokenizers import Tokenizer, decoders, models, pre_tokenizers
+    from transformers import PreTrainedTokenizerFast
+    vocab = {"<|endoftext|>": 0}
+    for i, ch in enumerate(sorted(pre_tokenizers.ByteLevel.alphabet())):
+        vocab[ch] = i + 1
+    tok = Tokenizer(models.BPE(vocab=vocab, merges=[]))
+    tok.pre_tokenizer = pre_tokenizers.ByteLevel(add_prefix_space=False)
+    tok.decoder = decoders.ByteLevel()
+    PreTrainedTokenizerFast(tokenizer_object=tok, eos_token="<|endoftext|>").save_pretrained(path)
+    return path

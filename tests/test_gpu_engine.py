@@ -263,3 +263,24 @@ def test_http_front_end_over_the_real_engine(mv):
     finally:
         loop.stop()
     assert eng.cache_manager.stats["free"] == 24
+
+
+def test_checkpoint_directory_with_its_tokenizer_end_to_end(mv, tmp_path):
+    """Directory in, text out: weights from safetensors, tokenizer from the same directory, greedy
+    continuation equal to the one an engine over the source model object produces."""
+    import os, sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from ckpt_util import write_byte_tokenizer, write_checkpoint
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.core.model_loader import load_tokenizer
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    src = build_synthetic_model(SHAPES["tiny-gqa"], "cpu", seed=21, norm_jitter=0.1)
+    path = write_byte_tokenizer(write_checkpoint(src, str(tmp_path / "ckpt"), "llama"))
+    kw = dict(max_batch_size=2, n_blocks=12, max_tokens=512, graph_batch_sizes=[1, 2], prefill_timeout=0.0)
+    prompts = ["The quick brown fox", "jumps over"]
+    got = InferenceEngine(path, **kw).generate(prompts, max_tokens=8, temperature=0.0)
+    want = InferenceEngine(model=src.to(DEV), tokenizer=load_tokenizer(path), **kw) \
+        .generate(prompts, max_tokens=8, temperature=0.0)
+    assert got == want and set(got) == set(prompts)
+    assert all(got[p].startswith(p) for p in prompts)     # the text holds the prompt, then the continuation

@@ -103,3 +103,15 @@ def test_errors(tmp_path):
     json.dump(hf, open(os.path.join(path, "config.json"), "w"))
     with pytest.raises(NotImplementedError, match="rope_scaling"):
         load_weights(path)
+
+
+def test_load_model_returns_the_directory_s_tokenizer(tmp_path):
+    """core/model_loader.py:7-26: tokenizer from local files only."""
+    from ckpt_util import write_byte_tokenizer
+    src = build_synthetic_model(SHAPES["tiny-gqa"])
+    path = write_checkpoint(src, str(tmp_path / "c"), "llama")
+    write_byte_tokenizer(path)
+    model, tok = load_model(path)
+    ids = tok.encode("héllo, wörld", add_special_tokens=True)
+    assert tok.decode(ids, skip_special_tokens=True) == "héllo, wörld"
+    assert max(ids) < model.config.vocab_size and tok.eos_token_id == 0
