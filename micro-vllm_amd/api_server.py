@@ -58,6 +58,11 @@ class EngineLoop:
         with self._lock:
             seq_id = self.engine.add_request(prompt, max_tokens, temperature, top_p)
             req.seq = next(s for s in reversed(self.engine.scheduler.waiting_queue) if s.seq_id == seq_id)
+            # the id is a hash of prompt and arrival time (core/engine.py:139-146): the same prompt
+            # twice within one clock tick would share it, and with it KV pages and completion
+            while seq_id in self._requests:
+                seq_id = (seq_id + 1) % (2 ** 32)
+            req.seq.seq_id = seq_id
             self._requests[seq_id] = req
             if on_token is not None:
                 self.engine.register_stream_callback(seq_id, on_token)

@@ -209,3 +209,24 @@ def test_two_ranks_run_the_same_steps_and_retire_the_same_sequences():
         assert ids == expected(prompt, 5)[1], prompt
     assert got[1][1] == freed0 and len(freed0) == 4
     assert got[1][2] == kinds0 and kinds0[0][0] == "prefill"
+
+
+def test_identical_prompts_in_one_clock_tick_get_distinct_ids(monkeypatch):
+    import time as _time
+    eng = RuleEngine()
+    loop = EngineLoop(eng)
+    frozen = _time.time()
+    monkeypatch.setattr("micro_vllm_amd.core.engine.time.time", lambda: frozen)
+    done = []
+    ids = [loop.submit("same prompt", 3, 0.0, 0.9, on_done=lambda s, e: done.append(s.seq_id)) for _ in range(3)]
+    monkeypatch.undo()
+    assert len(set(ids)) == 3
+    loop.start()
+    try:
+        for _ in range(1000):
+            if len(done) == 3:
+                break
+            _time.sleep(0.005)
+    finally:
+        loop.stop()
+    assert sorted(done) == sorted(ids) and sorted(eng.cache_manager.freed) == sorted(ids)
