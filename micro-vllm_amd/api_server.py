@@ -266,14 +266,18 @@ def main(argv=None):
     ap.add_argument("--max-batch-size", type=int, default=40)
     ap.add_argument("--max-prefill-tokens", type=int, default=2048)
     ap.add_argument("--max-tokens", type=int, default=4352, help="longest sequence a block-table row describes")
-    ap.add_argument("--kv-blocks", type=int, default=None, help="KV pages of 256 tokens (default 81)")
+    ap.add_argument("--kv-blocks", type=int, default=None,
+                    help="KV pages of 256 tokens (default: sized from the free device memory)")
+    ap.add_argument("--kv-fraction", type=float, default=0.9,
+                    help="share of the free device memory the KV pool takes when --kv-blocks is not given")
     ap.add_argument("--exact-rope", action="store_true")
     ap.add_argument("--trust-remote-code", action="store_true", help="for tokenizers shipped as Python")
     args = ap.parse_args(argv)
 
     from .core.engine import InferenceEngine
     engine = InferenceEngine(args.model_path, args.max_batch_size, args.max_prefill_tokens,
-                             n_blocks=args.kv_blocks, max_tokens=args.max_tokens,
+                             n_blocks=args.kv_blocks if args.kv_blocks is not None else "auto",
+                             kv_fraction=args.kv_fraction, max_tokens=args.max_tokens,
                              exact_rope=args.exact_rope, trust_remote_code=args.trust_remote_code)
     loop = EngineLoop(engine)
     logger.info("rank %d: model loaded on %s", get_rank(), engine.device)

@@ -40,9 +40,12 @@ class InferenceEngine:
                  max_prefill_tokens: int = 2048, *, model=None, tokenizer=None,
                  n_blocks: Optional[int] = None, max_tokens: int = 1024,
                  graph_batch_sizes: Optional[List[int]] = None, prefill_timeout: float = 0.02,
-                 exact_rope: bool = False, trust_remote_code: bool = False):
+                 exact_rope: bool = False, trust_remote_code: bool = False, kv_fraction: float = 0.9):
         """`max_tokens` is the longest sequence a block-table row can describe (the reference's
         KVCacheManager default, 1024, gives four columns - pass more for long contexts).
+        `n_blocks`: None = the reference's 81 pages (core/engine.py:53-57), a number, or "auto" =
+        `kv_fraction` of the device memory that is free once the weights are in place (on a
+        288 GB device an 8B model leaves room for more than a million cached tokens).
         `exact_rope` builds the rotary tables from fp32 positions; the default keeps the
         reference's bf16 positions (core/paged_attention.py:50-52), which merge neighbouring
         positions above 256 - with a trained checkpoint and long contexts pass True."""
@@ -74,19 +77,24 @@ class InferenceEngine:
         self.num_heads, self.kv_num_heads = heads // world, kv_heads // world
         self.intermediate_size = cfg.intermediate_size // world
 
-        blocks = n_blocks if n_blocks is not None else self.DEFAULT_MAX_BLOCKS
-        self.cache_manager = KVCacheManager(
-            n_blocks=blocks, block_size=self.DEFAULT_BLOCK_SIZE, n_layers=self.num_layers,
-            n_heads=self.kv_num_heads, head_size=self.head_size, dtype=self.dtype, device=self.device,
-            max_tokens=max_tokens, max_batch_size=max_batch_size)
         max_blocks = max(32, (max_tokens + 255) // 256)
         runner_args = dict(model=model, num_layers=self.num_layers, num_heads=self.num_heads,
                            head_size=self.head_size, kv_num_heads=self.kv_num_heads,
                            hidden_dim=cfg.hidden_size, intermediate_size=self.intermediate_size,
                            device=self.device, max_batch_size=max_batch_size, dtype=self.dtype,
                            max_blocks=max_blocks, exact_rope=exact_rope)
+        # the runners first: they put this rank's weights on the device, and a pool sized from
+        # what is left has to see that
         self.graph_runner = ModelGraphRunner(**runner_args)
         self.prefill_runner = ModelPrefillRunner(**runner_args)
+        if n_blocks == "auto":
+            blocks = self.auto_kv_blocks(kv_fraction)
+        else:
+            blocks = n_blocks if n_blocks is not None else self.DEFAULT_MAX_BLOCKS
+        self.cache_manager = KVCacheManager(
+            n_blocks=blocks, block_size=self.DEFAULT_BLOCK_SIZE, n_layers=self.num_layers,
+            n_heads=self.kv_num_heads, head_size=self.head_size, dtype=self.dtype, device=self.device,
+            max_tokens=max_tokens, max_batch_size=max_batch_size)
         self.scheduler = Scheduler(max_batch_size, max_prefill_tokens, tokenizer, prefill_timeout)
         self.sampler = Sampler()
 
@@ -101,6 +109,21 @@ class InferenceEngine:
         sizes = graph_batch_sizes or [b for b in (1, 2, 4, 8, 16, 32, 40) if b <= max_batch_size]
         self.scheduler.batch_sizes = [b for b in sizes if b <= max_batch_size] or [max_batch_size]
         self.graph_runner.capture(self.cache_manager, batch_sizes=self.scheduler.batch_sizes)
+
+    def auto_kv_blocks(self, fraction: float) -> int:
+        """Pages of DEFAULT_BLOCK_SIZE tokens (K and V, all layers, this rank's kv heads) that fit
+        into `fraction` of the currently free device memory; never fewer than the reference's pool."""
+        torch.cuda.synchronize()
+        free, _ = torch.cuda.mem_get_info()
+        per_block = 2 * self.DEFAULT_BLOCK_SIZE * self.kv_num_heads * self.head_size * 2 * self.num_layers
+        blocks = max(self.DEFAULT_MAX_BLOCKS, int(free * fraction) // per_block)
+        if get_world_size() > 1:
+            # every rank mirrors the same allocator state, so all take the smallest pool
+            from .inference_context import _comm_device
+            t = torch.tensor([blocks], dtype=torch.int64, device=_comm_device())
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+            blocks = int(t.item())
+        return blocks
 
     def shutdown(self):
         try:

@@ -284,3 +284,21 @@ def test_checkpoint_directory_with_its_tokenizer_end_to_end(mv, tmp_path):
         .generate(prompts, max_tokens=8, temperature=0.0)
     assert got == want and set(got) == set(prompts)
     assert all(got[p].startswith(p) for p in prompts)     # the text holds the prompt, then the continuation
+
+
+def test_kv_pool_sized_from_free_device_memory(mv):
+    """n_blocks="auto": the pool takes a share of what is free after the weights are in place."""
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES["tiny-gqa"]
+    tok = Tok(cfg.vocab_size)
+    free, _ = torch.cuda.mem_get_info()
+    eng = InferenceEngine(model=build_synthetic_model(cfg, "cpu", seed=5).to(DEV), tokenizer=tok,
+                          max_batch_size=2, n_blocks="auto", kv_fraction=0.002, max_tokens=512,
+                          graph_batch_sizes=[1, 2], prefill_timeout=0.0)
+    per_block = 2 * 256 * cfg.num_key_value_heads * cfg.head_dim * 2 * cfg.num_hidden_layers
+    total = eng.cache_manager.stats["free"]
+    assert total >= 81 and abs(total - int(free * 0.002) // per_block) <= max(81, total // 10)
+    out = eng.generate(["abc", "defg"], max_tokens=4, temperature=0.0)
+    assert len(out) == 2 and eng.cache_manager.stats["free"] == total
