@@ -58,6 +58,16 @@ class EngineLoop:
         with self._lock:
             seq_id = self.engine.add_request(prompt, max_tokens, temperature, top_p)
             req.seq = next(s for s in reversed(self.engine.scheduler.waiting_queue) if s.seq_id == seq_id)
+            # a prompt the scheduler can never place (longer than one prefill step may be, or than
+            # a block-table row can describe together with its continuation) is refused here:
+            # left in the queue it would wait for ever
+            n = len(req.seq.input_ids)
+            limit = min(self.engine.scheduler.max_prefill_tokens,
+                        getattr(self.engine.cache_manager, "max_tokens", 1 << 62) - max_tokens - 1)
+            if n > limit or n == 0:
+                self.engine.scheduler.waiting_queue.remove(req.seq)
+                raise ValueError(f"prompt of {n} tokens with max_tokens={max_tokens}: at most {limit} prompt "
+                                 "tokens fit (max_prefill_tokens / the block table's max_tokens)")
             # the id is a hash of prompt and arrival time (core/engine.py:139-146): the same prompt
             # twice within one clock tick would share it, and with it KV pages and completion
             while seq_id in self._requests:
@@ -200,7 +210,10 @@ def create_app(loop: EngineLoop, model_name: str = "model"):
         def done(seq, error):
             aio.call_soon_threadsafe(fut.set_result, (seq, error))
 
-        loop.submit(prompt, max_tokens, temperature, top_p, on_done=done)
+        try:
+            loop.submit(prompt, max_tokens, temperature, top_p, on_done=done)
+        except ValueError as e:
+            raise HTTPException(400, str(e))
         seq, error = await fut
         if error is not None:
             raise HTTPException(500, f"generation failed: {error}")
@@ -236,7 +249,10 @@ def create_app(loop: EngineLoop, model_name: str = "model"):
         def on_done(seq, error):
             aio.call_soon_threadsafe(queue.put_nowait, ("done", seq, error))
 
-        loop.submit(req.prompt, req.max_tokens, req.temperature, req.top_p, on_token, on_done)
+        try:
+            loop.submit(req.prompt, req.max_tokens, req.temperature, req.top_p, on_token, on_done)
+        except ValueError as e:
+            raise HTTPException(400, str(e))
 
         async def events():
             full_text = ""

@@ -106,6 +106,15 @@ def test_stream_emits_one_event_per_token(client):
     assert r["tokens"] == 2
 
 
+def test_prompts_that_can_never_be_scheduled_are_refused(client):
+    too_long = "x" * 2049                      # the scheduler's max_prefill_tokens is 2048
+    assert client.post("/generate", json={"prompt": too_long, "max_tokens": 2}).status_code == 400
+    assert client.post("/generate_stream", json={"prompt": too_long, "max_tokens": 2, "stream": True}).status_code == 400
+    assert client.post("/generate", json={"prompt": "", "max_tokens": 2}).status_code == 400
+    assert not client.engine.scheduler.waiting_queue and not client.loop._requests
+    assert client.post("/generate", json={"prompt": "x" * 2048, "max_tokens": 2}).json()["tokens"] == 2
+
+
 def test_a_failing_step_fails_its_requests_and_the_loop_goes_on():
     from starlette.testclient import TestClient
     eng = RuleEngine(fail_on="boom")
