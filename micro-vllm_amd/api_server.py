@@ -56,18 +56,9 @@ class EngineLoop:
                on_token: Optional[Callable] = None, on_done: Optional[Callable] = None) -> int:
         req = _Request(prompt, on_token, on_done)
         with self._lock:
+            # raises ValueError for a request that can never be scheduled (the handlers answer 400)
             seq_id = self.engine.add_request(prompt, max_tokens, temperature, top_p)
             req.seq = next(s for s in reversed(self.engine.scheduler.waiting_queue) if s.seq_id == seq_id)
-            # a prompt the scheduler can never place (longer than one prefill step may be, or than
-            # a block-table row can describe together with its continuation) is refused here:
-            # left in the queue it would wait for ever
-            n = len(req.seq.input_ids)
-            limit = min(self.engine.scheduler.max_prefill_tokens,
-                        getattr(self.engine.cache_manager, "max_tokens", 1 << 62) - max_tokens - 1)
-            if n > limit or n == 0:
-                self.engine.scheduler.waiting_queue.remove(req.seq)
-                raise ValueError(f"prompt of {n} tokens with max_tokens={max_tokens}: at most {limit} prompt "
-                                 "tokens fit (max_prefill_tokens / the block table's max_tokens)")
             # the id is a hash of prompt and arrival time (core/engine.py:139-146): the same prompt
             # twice within one clock tick would share it, and with it KV pages and completion
             while seq_id in self._requests:

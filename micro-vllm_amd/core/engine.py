@@ -138,6 +138,15 @@ class InferenceEngine:
         seq_id = hash(prompt + str(time.time())) % (2 ** 32)
         seq = Sequence(seq_id, prompt, self.tokenizer, max_tokens)
         seq.temperature, seq.top_p = temperature, top_p
+        # A prompt no prefill step may hold, or one whose continuation would run past the last
+        # block-table column, can never be served; the reference fails on it later, inside the
+        # scheduler (TypeError) or the cache manager.  Refused here, with the limits named.
+        n = len(seq.input_ids)
+        rows = self.cache_manager.max_seq_blocks * self.cache_manager.block_size
+        if n == 0 or n > self.scheduler.max_prefill_tokens or n + max_tokens + 1 > rows:
+            raise ValueError(
+                f"prompt of {n} tokens with max_tokens={max_tokens} cannot be scheduled: "
+                f"max_prefill_tokens={self.scheduler.max_prefill_tokens}, block table covers {rows} positions")
         self.scheduler.add_request(seq)
         return seq_id
 

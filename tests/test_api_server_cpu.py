@@ -26,6 +26,8 @@ class Tok:
 
 
 class Pages:
+    block_size, max_seq_blocks = 256, 16        # what the engine's intake check reads
+
     def __init__(self):
         self.freed = []
 

@@ -302,3 +302,21 @@ def test_kv_pool_sized_from_free_device_memory(mv):
     assert total >= 81 and abs(total - int(free * 0.002) // per_block) <= max(81, total // 10)
     out = eng.generate(["abc", "defg"], max_tokens=4, temperature=0.0)
     assert len(out) == 2 and eng.cache_manager.stats["free"] == total
+
+
+def test_requests_that_cannot_be_scheduled_are_refused_at_intake(mv):
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES["tiny-gqa"]
+    eng = InferenceEngine(model=build_synthetic_model(cfg, "cpu", seed=5).to(DEV), tokenizer=Tok(cfg.vocab_size),
+                          max_batch_size=2, max_prefill_tokens=64, n_blocks=12, max_tokens=512,
+                          graph_batch_sizes=[1, 2], prefill_timeout=0.0)
+    with pytest.raises(ValueError, match="max_prefill_tokens=64"):
+        eng.add_request("x" * 65, max_tokens=4)
+    with pytest.raises(ValueError, match="512 positions"):
+        eng.add_request("x" * 60, max_tokens=452)          # 60 + 452 + 1 > 512
+    with pytest.raises(ValueError):
+        eng.add_request("", max_tokens=4)
+    assert not eng.scheduler.waiting_queue
+    assert len(eng.generate(["x" * 64], max_tokens=447, temperature=0.0)) == 1   # exactly at both limits
