@@ -24,17 +24,16 @@ import time
 from typing import Callable, List, Optional
 
 from .core.inference_context import BatchInferenceContext
-from .core.parallel_config import get_rank, rank0
+from .core.parallel_config import get_rank, get_world_size, rank0
 
 logger = logging.getLogger("api_server")
 
 
 class _Request:
-    __slots__ = ("prompt", "on_token", "on_done", "seq", "t0")
+    __slots__ = ("on_done", "seq")
 
-    def __init__(self, prompt, on_token, on_done):
-        self.prompt, self.on_token, self.on_done = prompt, on_token, on_done
-        self.seq, self.t0 = None, time.time()
+    def __init__(self, on_done):
+        self.on_done, self.seq = on_done, None
 
 
 class EngineLoop:
@@ -54,7 +53,7 @@ class EngineLoop:
     # ---- called from any thread
     def submit(self, prompt: str, max_tokens: int, temperature: float, top_p: float,
                on_token: Optional[Callable] = None, on_done: Optional[Callable] = None) -> int:
-        req = _Request(prompt, on_token, on_done)
+        req = _Request(on_done)
         with self._lock:
             # raises ValueError for a request that can never be scheduled (the handlers answer 400)
             seq_id = self.engine.add_request(prompt, max_tokens, temperature, top_p)
@@ -108,6 +107,10 @@ class EngineLoop:
                 eng.step(ctx)
             except Exception as e:            # e.g. out of KV pages: fail these requests, keep serving
                 logger.exception("step failed")
+                if get_world_size() > 1:
+                    # the other ranks are inside the same step and expect its second message: there
+                    # is no way back into lockstep from here
+                    raise
                 self._fail(ctx.sequences, e)
                 continue
             ctx.broadcast()
