@@ -176,3 +176,20 @@ def test_two_rank_prefill_matches_the_oracle():
     err = (got[0][0] - want).abs()
     assert err.mean().item() <= 4e-3
     assert err.max().item() <= 4 * 2.0 ** -7 * float(want.abs().max())
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_are_captured_with_the_decode_step():
+    """The path several ranks take (all_reduce after the O and the down projection, step captured
+    through torch's graph) on one GPU: a one-rank RCCL group, the runner sharded as rank 0 of 2.
+    Runs in a child process so that this process never joins a process group."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "rehearse_rccl_graph.py"), "tiny-d128", "4"],
+                       capture_output=True, text=True, timeout=110, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "all_reduce calls per eager step 4 (expected 4)" in r.stdout
+    assert "graph captured: True (CUDAGraph)" in r.stdout and "bit for bit: True" in r.stdout
