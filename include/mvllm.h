@@ -5,7 +5,10 @@
  * strides in ELEMENTS, an explicit hipStream_t (passed as void*), and an int
  * return code (0 = ok, negative = mv_status below).  Nothing here allocates,
  * frees or synchronises: the caller owns every buffer, and all launches are
- * legal under HIP stream capture.  All tensors are bf16 unless a parameter
+ * legal under HIP stream capture.  The entry points keep no state on the device
+ * between calls except in the buffers the caller passes, so calls on different
+ * streams (or threads) are independent as long as they are given different
+ * workspaces.  All tensors are bf16 unless a parameter
  * says otherwise; accumulation is fp32.
  *
  * Each declaration names the reference call it stands in for
@@ -135,7 +138,8 @@ int mv_wgemm_postnorm(const void* x, int64_t ldx, const void* w_tiles, const voi
                       float eps, void* normed, int64_t ld_normed, int norm_flags, int m, int n, int k,
                       void* workspace, size_t workspace_bytes, mv_stream_t stream);
 
-/* Launch-shape knobs for experiments (no counterpart in the reference):
+/* Launch-shape knobs for experiments (no counterpart in the reference; process-wide, read once
+ * per call, safe to set from another thread):
  * key 0 = workgroups per CU the grid is sized for (1..8; 0 = planner, the default);
  * key 1 = forced number of k-slices per strip (0 = pick automatically);
  * key 2 = waves per workgroup of the M <= 4 kernel (8 or 16; 0 = planner);
@@ -163,7 +167,10 @@ int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const vo
 
 /* ---------------------------------------------------- paged attention */
 
-/* Bytes of fp32 workspace for split-KV partial results. */
+/* Bytes of workspace for the split-KV merge (0 for one split): a 1 MiB header of arrival
+ * tickets, then the splits' log-sum-exps and fp32 partial outputs.  The caller zero-fills the
+ * workspace ONCE, when it allocates it; every launch returns the tickets to zero, so the same
+ * workspace serves any later call, of any shape that fits. */
 size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_splits);
 
 /* How many KV splits the library would pick for this shape (ctx_hint = typical
@@ -194,6 +201,8 @@ int mv_paged_attn_tune(int key, int value);
  * block_table: int32 [bs, bt_stride] (-1 = unallocated, never dereferenced for
  * indices <= p / page unless the caller broke the contract, in which case the key is
  * skipped), out: [bs,Hq,D] contiguous.  D in {64,128}; Hq/Hkv in {1,2,4,8}.
+ * workspace: see mv_paged_attn_decode_workspace_bytes (zero-filled once by the caller; calls
+ * that may overlap on one GPU need a workspace each).
  * Replaces the flash_attn_with_kvcache call at core/layer/model_graph.py:161-168
  * (and core/paged_attention.py:281). */
 int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, const void* v_new,
@@ -246,8 +255,13 @@ int mv_store_kv(const void* key, const void* value, int64_t kv_stride_t, void* k
 
 /* ids[r] = argmax_c logits[r, c] over bf16 logits [rows, n] (row stride ld), lowest index on
  * ties; ids are int64.  The greedy (temperature -> 0) case of core/layer/sampler.py:21-43,
- * done on the device so the step needs no [bs,V] sort and no host round trip. */
-int mv_argmax(const void* logits, int64_t ld, int rows, int n, int64_t* ids, mv_stream_t stream);
+ * done on the device so the step needs no [bs,V] sort and no host round trip.
+ * workspace (optional, mv_argmax_workspace_bytes() bytes, 16-byte aligned, zero-filled once by
+ * the caller): where the parts of a long row meet when few rows are spread over many
+ * workgroups; without it every row gets one workgroup (same result, slower). */
+size_t mv_argmax_workspace_bytes(void);
+int mv_argmax(const void* logits, int64_t ld, int rows, int n, int64_t* ids, void* workspace,
+              size_t workspace_bytes, mv_stream_t stream);
 
 /* Stochastic pick, one launch per batch: for each row, scale by 1/temperature[r], keep the
  * min(top_k, n, 1024) largest logits, softmax over them, keep the sorted prefix whose inclusive

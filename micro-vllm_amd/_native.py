@@ -61,7 +61,8 @@ PROTOTYPES = {
     "mv_rope_store_prefill": (_I, [_P, _L, _P, _P, _I, _P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mv_paged_attn_prefill": (_I, [_P, _L, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _I, _I, _I, _I, _F, _P]),
     "mv_store_kv": (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "mv_argmax": (_I, [_P, _L, _I, _I, _P, _P]),
+    "mv_argmax_workspace_bytes": (_Z, []),
+    "mv_argmax": (_I, [_P, _L, _I, _I, _P, _P, _Z, _P]),
     "mv_sample_topk_topp": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P]),
     "mv_sample_or_greedy": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
     "mv_graph_begin_capture": (_I, [_P]),
@@ -124,3 +125,25 @@ def stream_ptr(stream=None):
 def ptr(t):
     """Device address of a tensor (None -> NULL)."""
     return None if t is None else t.data_ptr()
+
+
+_stream_ws = {}
+
+
+def stream_workspace(kind, device, nbytes):
+    """A zero-initialised device buffer of at least `nbytes` for kernels that meet in a workspace
+    (split merges, arrival tickets), one per (purpose, device, current stream): calls on different
+    streams never share one.  The library's kernels leave the ticket area zero after every launch,
+    so the buffer is zero-filled only when it is (re)allocated."""
+    import torch
+
+    if nbytes <= 0:
+        return None
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (kind, idx, torch.cuda.current_stream(idx).cuda_stream)
+    ws = _stream_ws.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+        _stream_ws[key] = ws
+    return ws

@@ -204,6 +204,8 @@ class ModelGraphRunner:
             need = max(need, L.mv_wgemm_postnorm_workspace_bytes(max_b, self.hidden_dim, k))
         self._gemm_ws = gemm_workspace(dev, max(need, 16))
         self._attn_ws = None
+        # this runner's own meeting place for the parts of the greedy pick (zero-initialised tickets)
+        self._argmax_ws = torch.zeros((L.mv_argmax_workspace_bytes() + 3) // 4, dtype=torch.float32, device=dev)
 
     # ------------------------------------------------------------------ pieces
     def _splits_uneven(self, bs, even):
@@ -231,7 +233,8 @@ class ModelGraphRunner:
                     b, self.num_heads, self.head_size,
                     max(L.mv_paged_attn_decode_pick_splits(b, self.kv_num_heads, self.head_size, ctx), 4))
                     for b in range(1, self.max_bs + 1))
-                self._attn_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.device)
+                # zero-filled: the workspace starts with the arrival tickets of the split merge
+                self._attn_ws = torch.zeros((need + 3) // 4, dtype=torch.float32, device=self.device)
         return ns
 
     def _qkv_proj(self, h, block, bs):
@@ -347,7 +350,7 @@ class ModelGraphRunner:
             for layer_idx in range(self.num_layers):
                 h = self._layer(h, layer_idx, bs, cache_manager)
             logits = self._head(h, bs)
-        greedy(logits, out=self._greedy)
+        greedy(logits, out=self._greedy, workspace=self._argmax_ws)
         if self.vocab_size % 8 == 0:
             sample(logits, self._samp_temp[:bs], self._samp_topp[:bs], min(self.decode_top_k, self.vocab_size),
                    uniforms=self._samp_u[:bs], out=self._picked, greedy_ids=self._greedy)

@@ -11,8 +11,10 @@ import torch
 from ... import _native as nv
 
 
-def greedy(logits: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
-    """logits [bs,V] bf16 -> int64 [bs] (first index on ties), no host synchronisation."""
+def greedy(logits: torch.Tensor, out: torch.Tensor = None, workspace: torch.Tensor = None) -> torch.Tensor:
+    """logits [bs,V] bf16 -> int64 [bs] (first index on ties), no host synchronisation.
+    `workspace`: zero-initialised float32 buffer of mv_argmax_workspace_bytes() where the parts of a
+    long row meet (default: one per device and stream)."""
     assert logits.is_cuda and logits.dtype == torch.bfloat16 and logits.dim() == 2
     assert logits.stride(1) == 1
     bs, v = logits.shape
@@ -20,7 +22,10 @@ def greedy(logits: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
         out = torch.empty(bs, dtype=torch.long, device=logits.device)
     assert out.dtype == torch.long and out.is_contiguous() and out.numel() >= bs
     ld = logits.stride(0) if bs > 1 else max(v, logits.stride(0))
+    if workspace is None:
+        workspace = nv.stream_workspace("argmax", logits.device, nv.lib().mv_argmax_workspace_bytes())
     nv.check("mv_argmax", nv.lib().mv_argmax(logits.data_ptr(), ld, bs, v, out.data_ptr(),
+                                             workspace.data_ptr(), workspace.numel() * 4,
                                              nv.stream_ptr()))
     return out[:bs]
 

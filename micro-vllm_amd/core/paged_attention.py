@@ -84,25 +84,18 @@ class PagedAttention(nn.Module):
         self._sin_pool = sin.to(torch.bfloat16).contiguous()
 
 
-_attn_ws = {}
-
-
 def _attn_workspace(device, nbytes):
-    if nbytes <= 0:
-        return None
-    key = (torch.device(device).index, )
-    ws = _attn_ws.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _attn_ws[key] = ws
-    return ws
+    """Split-KV workspace of the current stream (zero-initialised: its head holds arrival tickets)."""
+    return nv.stream_workspace("attn_decode", device, nbytes)
 
 
 def paged_attn_decode(q, k_new, v_new, k_cache, v_cache, cache_seqlens, block_table,
                       rotary_cos=None, rotary_sin=None, softmax_scale=None, num_splits=0,
                       out=None, workspace=None):
     """q: [B,Hq,D]; k_new/v_new: [B,Hkv,D] (views into a fused qkv row are fine);
-    caches [NB,page,Hkv,D]; returns out [B,Hq,D]."""
+    caches [NB,page,Hkv,D]; returns out [B,Hq,D].  `workspace` (float32, only used with more than
+    one split) must have been zero-filled when it was allocated: it starts with the arrival tickets
+    of the split merge, which every launch returns to zero."""
     assert q.is_cuda and q.dtype == torch.bfloat16
     B, Hq, D = q.shape
     Hkv = k_new.shape[1]

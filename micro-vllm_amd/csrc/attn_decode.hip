@@ -20,14 +20,22 @@
 // and keeping P exact halves the expected distance to any such kernel's result.)
 #include "common.h"
 
+#include <atomic>
+#include <stdio.h>
+
 namespace mv {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
 constexpr float kNegBig = -1.0e30f;
 // Arrival counters sit 256 bytes apart: tickets of different (sequence, kv head) pairs are then
-// served by different L2 channels instead of queueing on one cache line.
+// served by different L2 channels instead of queueing on one cache line.  They live in a
+// fixed-size header at the start of the caller's workspace (so two calls with two workspaces
+// never share a counter): zero when the caller hands the workspace over for the first time,
+// returned to zero by the merging workgroup of every launch.
 constexpr int kArriveStride = 64;
+constexpr int kMaxArrive = 4096;   // (sequence, kv head) pairs with a counter; more: second-launch merge
+constexpr size_t kArriveBytes = (size_t)kMaxArrive * kArriveStride * sizeof(unsigned int);  // 1 MiB
 
 struct AttnArgs {
     const uint16_t* q;
@@ -46,7 +54,8 @@ struct AttnArgs {
     uint16_t* out;
     float* part_lse;  // [bs*Hq*nsplit]
     float* part_o;    // [bs*Hq*nsplit*D]
-    unsigned int* arrive;  // [bs*Hkv] arrival counters (zero between launches); null = merge in a second kernel
+    unsigned int* arrive;  // [bs*Hkv] arrival counters in the workspace header (zero between launches);
+                           // null = merge in a second kernel
     int bs, hq, hkv;
     int page, page_shift, num_pages;
     float scale_log2;
@@ -874,24 +883,6 @@ __global__ __launch_bounds__(D) void paged_attn_combine_kernel(const float* __re
     out[bh * D + d] = (uint16_t)f32_to_bf16_bits(total);
 }
 
-// Arrival counters of the in-kernel split merge.  Zero at load time and returned to zero by the
-// merging workgroup, so a launch needs no memset; calls that overlap on one GPU would share
-// them and must not (one decode stream per process is the model here).
-constexpr int kMaxArrive = 16384;
-static __device__ unsigned int g_arrive[kMaxArrive * kArriveStride];
-
-static unsigned int* arrive_counters() {
-    static unsigned int* cached[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!cached[dev]) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_arrive)) != hipSuccess) return nullptr;
-        cached[dev] = (unsigned int*)p;
-    }
-    return cached[dev];
-}
-
 template <int D, int G, int W>
 static int launch_decode_w(const AttnArgs& a, hipStream_t s) {
     constexpr int kAT = W * 64;
@@ -936,15 +927,16 @@ static int launch_decode_mfma(const AttnArgs& a, hipStream_t s) {
     return check_launch();
 }
 
-static int g_tune_mfma = 0;  // matrix-core form: 0 = built-in rule, 1 = never, 2 = whenever it applies
+static std::atomic<int> g_tune_mfma{0};  // matrix-core form: 0 = built-in rule, 1 = never, 2 = whenever it applies
 
 // Measured on MI355X (tools/sweep_attn_mfma.py): with eight query heads per kv head the
 // matrix-core form wins everywhere (8 sequences x 1 kv head at ctx 8192: 16.1 us against 21.6);
 // with four the two forms are within 3 % of each other at every batch size (both stop at about
 // 5.6 TB/s), and the dot-product form keeps P in fp32.
 static bool use_mfma_form(int d, int g, int page) {
-    if (d != 128 || (g != 4 && g != 8) || (page % kMRows) != 0 || g_tune_mfma == 1) return false;
-    return g_tune_mfma == 2 || g == 8;
+    const int forced = g_tune_mfma.load(std::memory_order_relaxed);
+    if (d != 128 || (g != 4 && g != 8) || (page % kMRows) != 0 || forced == 1) return false;
+    return forced == 2 || g == 8;
 }
 
 template <int D>
@@ -960,8 +952,10 @@ static int dispatch_g(const AttnArgs& a, int g, hipStream_t s) {
 }
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-static int g_tune_inkernel_merge = 1;
-static int g_tune_target_blocks_x = 0;  // workgroups per CU the split count aims at (0 = built-in rule)
+// Experiment knobs (mv_paged_attn_tune): atomics, so a server thread reading them while another
+// thread flips one is not a data race; a call reads each of them once.
+static std::atomic<int> g_tune_inkernel_merge{1};
+static std::atomic<int> g_tune_target_blocks_x{0};  // workgroups per CU the split count aims at (0 = built-in rule)
 
 }  // namespace mv
 
@@ -970,7 +964,8 @@ extern "C" {
 size_t mv_paged_attn_decode_workspace_bytes(int bs, int hq, int d, int num_splits) {
     if (bs <= 0 || hq <= 0 || d <= 0 || num_splits <= 1) return 0;
     const size_t rows = (size_t)bs * hq * num_splits;
-    return mv::align_up(rows * sizeof(float), 256) + rows * d * sizeof(float);
+    // arrival counters | log-sum-exps | partial outputs
+    return mv::kArriveBytes + mv::align_up(rows * sizeof(float), 256) + rows * d * sizeof(float);
 }
 
 int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint) {
@@ -983,7 +978,7 @@ int mv_paged_attn_decode_pick_splits(int bs, int hkv, int d, int ctx_hint) {
     // sequences x 8 kv heads at ctx 4096 run 53.2 us at 2 splits against 58.1 at 4, 32 sequences
     // 94.9 us unsplit against 105.0 at 2.
     const int pairs = bs * hkv;
-    const int per_cu = mv::g_tune_target_blocks_x;  // 0 = the rule above
+    const int per_cu = mv::g_tune_target_blocks_x.load(std::memory_order_relaxed);  // 0 = the rule above
     const int cus = mv::num_cus();
     int ns;
     if (per_cu > 0) {
@@ -1023,15 +1018,15 @@ int mv_paged_attn_decode_form(int hq, int hkv, int d, int page) {
  * key 1 = workgroups per CU the automatic split count aims at (0 = built-in rule). */
 int mv_paged_attn_tune(int key, int value) {
     if (key == 0 && (value == 0 || value == 1)) {
-        mv::g_tune_inkernel_merge = value;
+        mv::g_tune_inkernel_merge.store(value, std::memory_order_relaxed);
         return MV_OK;
     }
     if (key == 1 && value >= 0 && value <= 8) {
-        mv::g_tune_target_blocks_x = value;
+        mv::g_tune_target_blocks_x.store(value, std::memory_order_relaxed);
         return MV_OK;
     }
     if (key == 2 && value >= 0 && value <= 2) {
-        mv::g_tune_mfma = value;
+        mv::g_tune_mfma.store(value, std::memory_order_relaxed);
         return MV_OK;
     }
     return MV_ERR_INVALID_ARG;
@@ -1099,12 +1094,13 @@ int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, c
         const size_t need = mv_paged_attn_decode_workspace_bytes(bs, hq, d, num_splits);
         if (!workspace || workspace_bytes < need || !aligned16(workspace)) return MV_ERR_WORKSPACE;
         const size_t rows = (size_t)bs * hq * num_splits;
-        a.part_lse = (float*)workspace;
-        a.part_o = (float*)((char*)workspace + align_up(rows * sizeof(float), 256));
+        a.part_lse = (float*)((char*)workspace + kArriveBytes);
+        a.part_o = (float*)((char*)workspace + kArriveBytes + align_up(rows * sizeof(float), 256));
     }
     a.arrive = nullptr;
-    if (num_splits > 1 && num_splits <= 128 && g_tune_inkernel_merge && bs * hkv <= kMaxArrive)
-        a.arrive = arrive_counters();
+    if (num_splits > 1 && num_splits <= 128 && g_tune_inkernel_merge.load(std::memory_order_relaxed) &&
+        bs * hkv <= kMaxArrive)
+        a.arrive = (unsigned int*)workspace;
     const int g = hq / hkv;
     hipStream_t s = (hipStream_t)stream;
     return d == 128 ? dispatch_g<128>(a, g, s) : dispatch_g<64>(a, g, s);

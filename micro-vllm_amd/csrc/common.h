@@ -82,6 +82,7 @@ __device__ __forceinline__ uint4 ld16_nt(const void* p) {
 
 // ---- host side -------------------------------------------------------------
 void set_last_hip_error(hipError_t e);
+void set_last_error_text(const char* text);  // what mv_last_hip_error() returns next
 inline int check_launch() {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

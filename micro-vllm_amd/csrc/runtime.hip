@@ -13,6 +13,11 @@ void set_last_hip_error(hipError_t e) {
     g_last_err[sizeof(g_last_err) - 1] = 0;
 }
 
+void set_last_error_text(const char* text) {
+    strncpy(g_last_err, text ? text : "", sizeof(g_last_err) - 1);
+    g_last_err[sizeof(g_last_err) - 1] = 0;
+}
+
 int num_cus() {
     static int cached[64] = {0};
     int dev = 0;

@@ -56,16 +56,17 @@ __global__ __launch_bounds__(kAmThreads) void argmax_kernel(const uint16_t* __re
 }
 
 // Few rows: one workgroup per row would leave the chip idle and read a 128k-entry row through a
-// single CU (about 15 us).  The row is cut into parts, one workgroup each; partial results go to a
-// fixed scratch array with write-through stores, and the workgroup that draws the last arrival
-// ticket of a row merges them.  The merge is a maximum under a total order (value, then lowest
+// single CU (about 15 us).  The row is cut into parts, one workgroup each; partial results go to the
+// caller's workspace (tickets | values | indices) with write-through stores, and the workgroup that
+// draws the last arrival ticket of a row merges them.  The tickets are zero when the caller hands
+// the workspace over for the first time and are returned to zero by every launch.  The merge is a maximum under a total order (value, then lowest
 // index), so the result does not depend on arrival order.
 constexpr int kAmPartThreads = 256;
 constexpr int kAmMaxParts = 64;
 constexpr int kAmMaxRows = 64;
-static __device__ float g_am_val[kAmMaxRows * kAmMaxParts];
-static __device__ int g_am_idx[kAmMaxRows * kAmMaxParts];
-static __device__ unsigned int g_am_ticket[kAmMaxRows * 64];  // 256 bytes apart; zero between launches
+constexpr size_t kAmTicketBytes = (size_t)kAmMaxRows * 64 * sizeof(unsigned int);  // 256 bytes apart
+constexpr size_t kAmPartBytes = (size_t)kAmMaxRows * kAmMaxParts * 4;
+constexpr size_t kAmWorkspaceBytes = kAmTicketBytes + 2 * kAmPartBytes;
 
 struct AmScratch {
     float* val;
@@ -136,22 +137,10 @@ __global__ __launch_bounds__(kAmPartThreads) void argmax_parts_kernel(const uint
     if (lane == 0) ids[rowi] = bi == 0x7fffffff ? 0 : bi;  // all-NaN row: index 0
 }
 
-static bool am_scratch(AmScratch& sc) {
-    static AmScratch cached[64];
-    static bool have[64] = {false};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if (!have[dev]) {
-        void *v = nullptr, *i = nullptr, *t = nullptr;
-        if (hipGetSymbolAddress(&v, HIP_SYMBOL(g_am_val)) != hipSuccess ||
-            hipGetSymbolAddress(&i, HIP_SYMBOL(g_am_idx)) != hipSuccess ||
-            hipGetSymbolAddress(&t, HIP_SYMBOL(g_am_ticket)) != hipSuccess)
-            return false;
-        cached[dev] = AmScratch{(float*)v, (int*)i, (unsigned int*)t};
-        have[dev] = true;
-    }
-    sc = cached[dev];
-    return true;
+static AmScratch am_scratch(void* workspace) {
+    unsigned char* p = (unsigned char*)workspace;
+    return AmScratch{(float*)(p + kAmTicketBytes), (int*)(p + kAmTicketBytes + kAmPartBytes),
+                     (unsigned int*)p};
 }
 
 // ---------------------------------------------------------------- top-k / top-p sampling
@@ -430,17 +419,19 @@ extern "C" int mv_sample_or_greedy(const void* logits, int64_t ld, int rows, int
     return mv::check_launch();
 }
 
-extern "C" int mv_argmax(const void* logits, int64_t ld, int rows, int n, int64_t* ids,
-                         mv_stream_t stream) {
+extern "C" size_t mv_argmax_workspace_bytes(void) { return mv::kAmWorkspaceBytes; }
+
+extern "C" int mv_argmax(const void* logits, int64_t ld, int rows, int n, int64_t* ids, void* workspace,
+                         size_t workspace_bytes, mv_stream_t stream) {
     if (rows == 0 && n > 0) return MV_OK;
     if (!logits || !ids || rows < 0 || n <= 0 || ld < n) return MV_ERR_INVALID_ARG;
     if (!mv::aligned16(logits) || (ld % 8) != 0) return MV_ERR_INVALID_ARG;
-    // few long rows: several workgroups per row (calls that overlap on one GPU would share the
-    // scratch and must not - one decode stream per process is the model here)
+    // few long rows: several workgroups per row, meeting in the caller's workspace (without one,
+    // or with too small a one, every row gets a single workgroup: same result, slower)
     const int nvec = n >> 3;
-    mv::AmScratch sc;
-    if (rows <= mv::kAmMaxRows && rows * 8 <= mv::num_cus() && nvec >= 4 * mv::kAmPartThreads &&
-        mv::am_scratch(sc)) {
+    if (workspace && workspace_bytes >= mv::kAmWorkspaceBytes && mv::aligned16(workspace) &&
+        rows <= mv::kAmMaxRows && rows * 8 <= mv::num_cus() && nvec >= 4 * mv::kAmPartThreads) {
+        const mv::AmScratch sc = mv::am_scratch(workspace);
         int parts = mv::num_cus() / (2 * rows);
         if (parts > mv::kAmMaxParts) parts = mv::kAmMaxParts;
         const int most = nvec / mv::kAmPartThreads;  // at least one 16-byte load per thread

@@ -23,17 +23,20 @@
 // t = bf16(t + bias); t = bf16(t + residual); SWIGLU: out = bf16(silu(gate_t) * up_t).
 #include "common.h"
 
+#include <atomic>
+
 namespace mv {
 
 constexpr int kGW = 8;           // waves per workgroup, MFMA form
 constexpr int kGT = kGW * kWave;
 constexpr int kMaxKsplit = 8;
 
-static int g_tune_bpc = 0;      // workgroups per CU the grid is sized for (0 = planner)
-static int g_tune_waves = 0;    // waves per workgroup of the dot form: 8 or 16 (0 = planner)
-static int g_tune_sg = 0;       // strips per workgroup of the MFMA form: 1, 2 or 4 (0 = planner)
-static int g_tune_ksplit = 0;   // 0 = heuristic
-static int g_tune_contig = 0;   // dot form: consecutive tiles per wave
+// Experiment knobs (mv_wgemm_tune).  Atomics: a thread may set one while another is inside a call.
+static std::atomic<int> g_tune_bpc{0};      // workgroups per CU the grid is sized for (0 = planner)
+static std::atomic<int> g_tune_waves{0};    // waves per workgroup of the dot form: 8 or 16 (0 = planner)
+static std::atomic<int> g_tune_sg{0};       // strips per workgroup of the MFMA form: 1, 2 or 4 (0 = planner)
+static std::atomic<int> g_tune_ksplit{0};   // 0 = heuristic
+static std::atomic<int> g_tune_contig{0};   // dot form: consecutive tiles per wave
 
 enum { kProNone = 0, kProNorm = 1, kProAddNorm = 2 };
 
@@ -732,8 +735,8 @@ static int pick_ksplit(int m, int nt, int kt) {
         const int sg = mfma_strip_group((m + 15) / 16, nt);
         nt = (nt + sg - 1) / sg;
     }
-    if (g_tune_ksplit > 0) {
-        int ks = g_tune_ksplit;
+    if (const int forced = g_tune_ksplit; forced > 0) {
+        int ks = forced;
         while (ks > 1 && (kt % ks) != 0) --ks;
         return ks;
     }
@@ -803,7 +806,7 @@ static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
 // (strip, row block) pair, 128 KiB for four strips of four row blocks
 static int mfma_strip_group(int mb, int nt) {
     const int most = 4;
-    if (g_tune_sg == 1 || g_tune_sg == 2 || g_tune_sg == 4) return g_tune_sg;
+    if (const int forced = g_tune_sg; forced == 1 || forced == 2 || forced == 4) return forced;
     // From sweeps (tools/sweep_mfma_gemv.py).  Two or more row blocks of x: always the widest
     // group - the x traffic out of L2 dominates otherwise (M=32, down projection: 41.7 us with
     // single strips against 25.9 us with groups of four).  One row block: the largest group that
@@ -905,8 +908,9 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     // Sixteen waves only pay when nearly every CU has a strip and the strip is long: shards with
     // short k (K=1792: 4.8 vs 5.8 us) or few strips (48: 5.4 vs 5.8) are faster with eight.
     const bool one_long_strip_per_cu = a.nunits <= cus && a.nunits * 8 >= cus * 7 && a.kt >= 128;
-    int waves = g_tune_waves ? g_tune_waves : (one_long_strip_per_cu ? 16 : 8);
-    int bpc = g_tune_bpc ? g_tune_bpc : (m <= 4 && waves == 8 ? 2 : 1);
+    const int forced_waves = g_tune_waves, forced_bpc = g_tune_bpc;
+    int waves = forced_waves ? forced_waves : (one_long_strip_per_cu ? 16 : 8);
+    int bpc = forced_bpc ? forced_bpc : (m <= 4 && waves == 8 ? 2 : 1);
     if (m <= 4) {
         // LDS limits co-residency; never size the grid past what fits
         const size_t lds = (size_t)m * k * 2 + 16 + (size_t)waves * m * 64;

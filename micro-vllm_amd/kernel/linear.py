@@ -63,15 +63,9 @@ _workspaces = {}
 
 
 def gemm_workspace(device, nbytes: int) -> Optional[torch.Tensor]:
-    """One grow-only fp32 slab buffer per device (k-split partial sums)."""
-    if nbytes <= 0:
-        return None
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    ws = _workspaces.get(key)
-    if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
-        _workspaces[key] = ws
-    return ws
+    """One grow-only fp32 slab buffer per device and stream (k-split partial sums), so that
+    projections issued on different streams never add into each other's slabs."""
+    return nv.stream_workspace("wgemm", device, nbytes)
 
 
 def wgemm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,

@@ -319,3 +319,36 @@ def test_matrix_core_form_merge_kernels_agree_and_poison_is_ignored(matrix_core_
     for splits, lst in outs.items():
         assert torch.equal(lst[0], lst[1]) and torch.equal(lst[0], lst[2]), splits
     test_slots_that_do_not_count_may_hold_anything(None, 128, 8, 2)
+
+
+def test_calls_on_two_streams_do_not_share_state(mv):
+    """Two split-KV launches in flight at once on two streams, each with its own workspace (the
+    default workspace is per stream): every output equals the one a lone call produces.  The split
+    merge keeps its arrival tickets in the workspace, so nothing on the device is shared."""
+    from micro_vllm_amd.core.paged_attention import paged_attn_decode
+
+    cases = [make_case(4, 8, 2, 128, 256, [4096, 3000, 4000, 2500], seed=71),
+             make_case(3, 8, 2, 128, 256, [4095, 3500, 100], seed=72)]
+    dev = []
+    for c in cases:
+        dev.append({k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in c.items()})
+
+    def launch(d, kc, vc):
+        return paged_attn_decode(d["q"][:, 0], d["k"][:, 0], d["v"][:, 0], kc, vc, d["seqlens"], d["bt"],
+                                 d["cos"], d["sin"], num_splits=16)
+
+    alone = [launch(d, d["k_cache"].clone(), d["v_cache"].clone()).clone() for d in dev]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    caches = [(d["k_cache"].clone(), d["v_cache"].clone()) for d in dev]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for _ in range(25):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                outs[i].append(launch(dev[i], *caches[i]).clone())
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        for o in outs[i]:
+            assert torch.equal(o, alone[i])
+        check_output(outs[i][0], cases[i], what=f"stream {i}")

@@ -81,3 +81,29 @@ def test_greedy_is_first_maximum(mv, rows, v):
     y = torch.full((1, v), -3.0, dtype=torch.bfloat16)
     y[0, v - 3] = 5.0
     assert int(greedy(y.to("cuda")).item()) == v - 3
+
+
+def test_greedy_on_two_streams_and_without_workspace(mv):
+    """The parts of a long row meet in the caller's workspace: two picks in flight on two streams
+    (each stream has its own default workspace) do not disturb each other, and a call without a
+    workspace (one workgroup per row) returns the same ids."""
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.core.layer.sampler import greedy
+
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, 128256, generator=g).to(torch.bfloat16).to("cuda") for _ in range(2)]
+    want = [x.float().argmax(-1) for x in xs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for _ in range(50):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                outs[i].append(greedy(xs[i]).clone())
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        assert all(torch.equal(o, want[i]) for o in outs[i])
+        ids = torch.zeros(2, dtype=torch.long, device="cuda")
+        nv.check("mv_argmax", nv.lib().mv_argmax(xs[i].data_ptr(), xs[i].stride(0), 2, 128256,
+                                                 ids.data_ptr(), None, 0, nv.stream_ptr()))
+        assert torch.equal(ids, want[i])
