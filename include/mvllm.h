@@ -8,7 +8,7 @@
  * legal under HIP stream capture.  The entry points keep no state on the device
  * between calls except in the buffers the caller passes, so calls on different
  * streams (or threads) are independent as long as they are given different
- * workspaces.  All tensors are bf16 unless a parameter
+ * workspaces; the one exception is mv_paged_attn_decode_noalloc, which says so.  All tensors are bf16 unless a parameter
  * says otherwise; accumulation is fp32.
  *
  * Each declaration names the reference call it stands in for
@@ -211,6 +211,23 @@ int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, c
                          const int32_t* block_table, int bt_stride, void* out, void* workspace,
                          size_t workspace_bytes, int bs, int hq, int hkv, int d, int page,
                          int num_pages, float scale, int num_splits, mv_stream_t stream);
+
+/* mv_paged_attn_decode for callers that cannot allocate device memory (code under HIP stream
+ * capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels and the same
+ * results, bit for bit, with the split-KV workspace in an 8 MiB array that is part of the
+ * library's device image instead of a caller buffer.  It has no counterpart in the reference.
+ * The call allocates and frees nothing.  Limit: mv_paged_attn_decode_workspace_bytes(bs, hq, d,
+ * num_splits) <= 8 MiB (e.g. 32 rows x 32 heads x 4 splits at d = 128), else MV_ERR_WORKSPACE
+ * with the sizes in mv_last_hip_error().  Every GPU holds one copy of the array for the life of
+ * the process and every call on a GPU uses it: calls that overlap on one GPU (two streams, two
+ * threads) race and must not be made.  The first call on a device looks the array's address up
+ * (make it outside stream capture). */
+int mv_paged_attn_decode_noalloc(const void* q, int64_t q_stride_b, const void* k_new,
+                                 const void* v_new, int64_t kv_stride_b, void* k_cache, void* v_cache,
+                                 const void* rot_cos, const void* rot_sin, int rot_max_pos,
+                                 const int32_t* cache_seqlens, const int32_t* block_table,
+                                 int bt_stride, void* out, int bs, int hq, int hkv, int d, int page,
+                                 int num_pages, float scale, int num_splits, mv_stream_t stream);
 
 /* ---- prefill (many tokens per sequence) ---- */
 

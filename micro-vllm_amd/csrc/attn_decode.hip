@@ -1107,3 +1107,77 @@ int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, c
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- the entry point that allocates nothing
+// For callers that cannot allocate device memory (code under stream capture, serving loops,
+// harnesses that forbid it): mv_paged_attn_decode with the split-KV workspace (arrival counters,
+// log-sum-exps, partial outputs) in a fixed array of the library instead of a caller buffer.
+// Every GPU the library runs on holds its own copy of the array, at its own address, until the
+// process ends; every call on a GPU uses that GPU's copy, so calls that overlap on one GPU (two
+// streams, two threads) race on it and must not be made.
+namespace mv {
+
+constexpr size_t kScratchBytes = (size_t)8 << 20;  // 8 MiB: 1 MiB of counters + 7 MiB of partials
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+// Device address of `scratch` on the current device (the array's name is only a host-side handle:
+// it must never be passed to a kernel or to a memset).  Resolved once per device.
+static unsigned char* scratch_on_current_device() {
+    static std::atomic<unsigned char*> cached[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= 64) {
+        set_last_hip_error(e != hipSuccess ? e : hipErrorInvalidDevice);
+        return nullptr;
+    }
+    unsigned char* p = cached[dev].load(std::memory_order_acquire);
+    if (!p) {
+        void* sym = nullptr;
+        e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !sym) {
+            set_last_hip_error(e != hipSuccess ? e : hipErrorInvalidSymbol);
+            return nullptr;
+        }
+        p = (unsigned char*)sym;
+        cached[dev].store(p, std::memory_order_release);
+    }
+    return p;
+}
+
+}  // namespace mv
+
+extern "C" int mv_paged_attn_decode_noalloc(const void* q, int64_t q_stride_b, const void* k_new,
+                                            const void* v_new, int64_t kv_stride_b, void* k_cache,
+                                            void* v_cache, const void* rot_cos, const void* rot_sin,
+                                            int rot_max_pos, const int32_t* cache_seqlens,
+                                            const int32_t* block_table, int bt_stride, void* out, int bs,
+                                            int hq, int hkv, int d, int page, int num_pages, float scale,
+                                            int num_splits, mv_stream_t stream) {
+    using namespace mv;
+    if (bs <= 0 || hq <= 0 || hkv <= 0 || d <= 0 || num_splits <= 0) return MV_ERR_INVALID_ARG;
+    const size_t need = mv_paged_attn_decode_workspace_bytes(bs, hq, d, num_splits);
+    if (need > kScratchBytes) {
+        char msg[200];
+        snprintf(msg, sizeof(msg),
+                 "mv_paged_attn_decode_noalloc: %d rows x %d heads x %d splits need %zu bytes of split "
+                 "partials, the built-in scratch holds %zu; use fewer splits or mv_paged_attn_decode",
+                 bs, hq, num_splits, need, kScratchBytes);
+        set_last_error_text(msg);
+        return MV_ERR_WORKSPACE;
+    }
+    unsigned char* ws = scratch_on_current_device();
+    if (!ws) return MV_ERR_LAUNCH;
+    if (num_splits > 1) {
+        // the array keeps what the last call left: the counters this call uses must start at zero
+        // (a completed call leaves them so; one that was cut short may not have)
+        const size_t pairs = (size_t)bs * hkv < (size_t)kMaxArrive ? (size_t)bs * hkv : (size_t)kMaxArrive;
+        hipError_t e = hipMemsetAsync(ws, 0, pairs * kArriveStride * sizeof(unsigned int), (hipStream_t)stream);
+        if (e != hipSuccess) {
+            set_last_hip_error(e);
+            return MV_ERR_LAUNCH;
+        }
+    }
+    return mv_paged_attn_decode(q, q_stride_b, k_new, v_new, kv_stride_b, k_cache, v_cache, rot_cos, rot_sin,
+                                rot_max_pos, cache_seqlens, block_table, bt_stride, out, ws, kScratchBytes, bs,
+                                hq, hkv, d, page, num_pages, scale, num_splits, stream);
+}
