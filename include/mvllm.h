@@ -101,11 +101,18 @@ enum {
     MV_GEMM_SWIGLU = 1, /* W rows are up/gate interleaved by 8 (mv_interleave_rows8);
                            y is [M, N/2] = swiglu(bf16(x @ W^T)), i.e. the matmul
                            + swiglu_gemm pair of model_graph.py:183-184 in one pass */
-    MV_GEMM_OUT_F32 = 2 /* y is fp32 [M,N]: the un-rounded accumulators (tests) */
+    MV_GEMM_OUT_F32 = 2, /* y is fp32 [M,N]: the un-rounded accumulators (tests) */
+    MV_GEMM_SLABS = 4    /* y is not written (may be NULL): the product is left in `workspace` as
+                            mv_wgemm_slab_count(m, n, k) fp32 slabs [slab][M][N] whose sum, added in
+                            slab order, is x @ W^T - for a caller whose next kernel adds them
+                            (mv_allreduce_addnorm).  Workspace: mv_wgemm_postnorm_workspace_bytes. */
 };
 int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
              const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n, int k,
              void* workspace, size_t workspace_bytes, int flags, mv_stream_t stream);
+
+/* Number of slabs an MV_GEMM_SLABS call leaves for this problem (>= 1). */
+int mv_wgemm_slab_count(int m, int n, int k);
 
 /* mv_wgemm with the input transform of the preceding norm kernel folded in (1 <= M <= 4):
  *   add_r == NULL:  x' = rmsnorm(x) * ln_w                       (mv_rmsnorm, then mv_wgemm)
@@ -298,6 +305,50 @@ int mv_sample_topk_topp(const void* logits, int64_t ld, int rows, int n, const f
 int mv_sample_or_greedy(const void* logits, int64_t ld, int rows, int n, const float* temperatures,
                         const float* top_ps, int top_k, const float* uniforms,
                         const int64_t* greedy_ids, int64_t* ids, mv_stream_t stream);
+
+/* ------------------------------------------- tensor-parallel all-reduce */
+
+/* One-shot all-reduce for the small [rows, n] bf16 messages of a tensor-parallel decode step, among
+ * the (at most 8) GPUs of one node, one process per GPU.  Every rank pushes its partial into every
+ * rank's exchange buffer over the direct xGMI links and sums what arrived in its own buffer in rank
+ * order (fp32, rounded to bf16 once): all ranks get the same bits.  Stands in for
+ * core/parallel_config.py:69-74 all_reduce at core/layer/model_graph.py:210,219; messages beyond the
+ * communicator's capacity (prefill) stay with RCCL.
+ *
+ * Set-up, once per process (these three allocate / map device memory; the step calls do not):
+ *   mv_allreduce_init        exchange buffer for messages of up to max_rows x max_n (max_rows <= 64,
+ *                            max_n <= 8192, a multiple of 8) on the current device;
+ *   mv_allreduce_get_handle  mv_allreduce_handle_bytes() bytes to pass to the other ranks by any host
+ *                            channel (e.g. torch.distributed.all_gather_object);
+ *   mv_allreduce_connect     `handles` = all ranks' handles in rank order; maps the peers' buffers.
+ * The step calls take the stream, never synchronise and are legal under stream capture: flags carry an
+ * epoch kept in device memory that only grows, so a captured step can be replayed.  All ranks must
+ * issue the same sequence of calls with the same `rows`.  A rank that waits longer than
+ * MVLLM_ALLREDUCE_TIMEOUT_MS (default 10 s) for a peer gives up, finishes with a wrong sum and sets
+ * the status word mv_allreduce_status reads (0 = no timeout so far; synchronising call). */
+size_t mv_allreduce_handle_bytes(void);
+int mv_allreduce_init(int rank, int world, int max_rows, int max_n, void** comm_out);
+int mv_allreduce_get_handle(void* comm, void* handle_out);
+int mv_allreduce_connect(void* comm, const void* handles);
+int mv_allreduce_status(void* comm, int* status_out);
+int mv_allreduce_destroy(void* comm);
+
+/* out = bf16(sum over ranks of in), [rows, n] bf16; out may alias in. */
+int mv_allreduce_step(void* comm, const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
+                      int n, mv_stream_t stream);
+
+/* The all-reduce together with what a decoder block does next (core/layer/model_graph.py:210-213 and
+ * :219 + :143 of the following block), one launch:
+ *   t = bf16(sum over ranks of partial);  s = t + residual;  y = bf16(s);
+ *   normed = bf16((float(y) * rrms) * ln_w),  rrms = 1 / sqrt(mean(s^2) + eps)
+ * (mean over the unrounded s, or over y as stored with MV_NORM_VAR_FROM_ROUNDED: the two cases of
+ * mv_wgemm_postnorm).  This rank's partial is either `in` (bf16 rows) or, with in == NULL, the sum of
+ * the `ksplit` fp32 slabs [ksplit][rows][n] an MV_GEMM_SLABS projection left, rounded to bf16 - what
+ * that projection's bf16 output would have been.  residual, y and (ln_w, normed) are optional. */
+int mv_allreduce_addnorm(void* comm, const void* in, int64_t ld_in, const float* slabs, int ksplit,
+                         const void* residual, int64_t ld_res, void* y, int64_t ldy, const void* ln_w,
+                         float eps, void* normed, int64_t ld_normed, int norm_flags, int rows, int n,
+                         mv_stream_t stream);
 
 /* ------------------------------------------------------------ hipGraph */
 

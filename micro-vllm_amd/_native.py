@@ -21,6 +21,7 @@ MV_ERR_GRAPH = -5
 MV_GEMM_DEFAULT = 0
 MV_GEMM_SWIGLU = 1
 MV_GEMM_OUT_F32 = 2
+MV_GEMM_SLABS = 4
 MV_NORM_VAR_FROM_ROUNDED = 1
 
 _P = c_void_p
@@ -46,6 +47,7 @@ PROTOTYPES = {
     "mv_wgemm": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P, _Z, _I, _P]),
     "mv_wgemm_norm": (_I, [_P, _L, _P, _L, _P, _F, _P, _L, _I, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P,
                            _Z, _I, _P]),
+    "mv_wgemm_slab_count": (_I, [_I, _I, _I]),
     "mv_wgemm_postnorm_workspace_bytes": (_Z, [_I, _I, _I]),
     "mv_wgemm_postnorm": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _P, _F, _P, _L, _I, _I, _I, _I, _P, _Z, _P]),
     "mv_paged_attn_decode_workspace_bytes": (_Z, [_I, _I, _I, _I]),
@@ -67,6 +69,14 @@ PROTOTYPES = {
     "mv_argmax": (_I, [_P, _L, _I, _I, _P, _P, _Z, _P]),
     "mv_sample_topk_topp": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P]),
     "mv_sample_or_greedy": (_I, [_P, _L, _I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "mv_allreduce_handle_bytes": (_Z, []),
+    "mv_allreduce_init": (_I, [_I, _I, _I, _I, ctypes.POINTER(c_void_p)]),
+    "mv_allreduce_get_handle": (_I, [_P, _P]),
+    "mv_allreduce_connect": (_I, [_P, _P]),
+    "mv_allreduce_status": (_I, [_P, ctypes.POINTER(c_int)]),
+    "mv_allreduce_destroy": (_I, [_P]),
+    "mv_allreduce_step": (_I, [_P, _P, _L, _P, _L, _I, _I, _P]),
+    "mv_allreduce_addnorm": (_I, [_P, _P, _L, _P, _I, _P, _L, _P, _L, _P, _F, _P, _L, _I, _I, _I, _P]),
     "mv_graph_begin_capture": (_I, [_P]),
     "mv_graph_end_capture": (_I, [_P, ctypes.POINTER(c_void_p)]),
     "mv_graph_launch": (_I, [_P, _P]),

@@ -24,6 +24,7 @@ SOURCES = [
     "attn_prefill.hip",
     "gemm_prefill.hip",
     "sampler.hip",
+    "allreduce.hip",
 ]
 
 # -ffp-contract=off: rounding is part of the parity contract; FMAs are written explicitly

@@ -23,7 +23,7 @@ from .. import parallel_config as pc
 from ..paged_attention import PagedAttention, paged_attn_decode
 from ... import _native as nv
 from ...kernel.linear import (StreamedWeight, add_, embedding, gemm_workspace, wgemm, wgemm_norm,
-                              wgemm_postnorm)
+                              wgemm_postnorm, wgemm_slabs)
 from ...kernel.rmsnorm_add import rmsnorm_
 from ...kernel.rmsnorm_residual import rmsnorm_residual_gemm
 from ...kernel.swiglu import swiglu_gemm
@@ -84,14 +84,23 @@ class ModelGraphRunner:
     def __init__(self, model, num_layers: int, num_heads: int, head_size: int, kv_num_heads: int,
                  hidden_dim: int, intermediate_size: int, device: str, max_batch_size: int = 32,
                  dtype: torch.dtype = torch.bfloat16, top_k: int = 1000, fused: bool = True,
-                 max_blocks: int = 32, exact_rope: bool = False, release_source_weights: bool = False):
+                 max_blocks: int = 32, exact_rope: bool = False, release_source_weights: bool = False,
+                 reducer=None, tp_rank: int = None, tp_world: int = None):
         """num_heads / kv_num_heads / intermediate_size are the PER-RANK values (already divided
         by the tensor-parallel world size), intermediate_size counting gate and up together,
-        exactly as the reference's engine passes them (core/engine.py:108-114)."""
+        exactly as the reference's engine passes them (core/engine.py:108-114).
+
+        `reducer` (kernel/allreduce.py interface) replaces the process group's reduction, and
+        `tp_rank` / `tp_world` the process group's rank and size: a single process can then run
+        the step of any one rank of a tensor-parallel group (tests, per-rank benchmarks)."""
         assert dtype == torch.bfloat16, "the HIP path computes in bf16 storage / fp32 accumulate"
         self.model = model
         self.num_layers = num_layers
         self.rank, self.world_size = pc.get_rank(), pc.get_world_size()
+        if tp_world is not None:
+            assert reducer is not None and 0 <= tp_rank < tp_world
+            self.rank, self.world_size = tp_rank, tp_world
+        self._reducer = reducer
         self.num_heads = num_heads
         self.kv_num_heads = kv_num_heads
         self.intermediate_size = intermediate_size
@@ -110,6 +119,8 @@ class ModelGraphRunner:
                                         rope_base=float(getattr(model.config, "rope_theta", 10000.0)))
         self.prepare_weights()
         self._alloc_bufs()
+        if self.world_size > 1 and self._reducer is None:
+            self._reducer = pc.tensor_parallel_reducer(min(max_batch_size, 64), hidden_dim)
         self._graphs: Dict[int, HipGraph] = {}
         # second graph per batch size, captured with a finer attention split: replayed when the
         # rows of a step differ much in length (the longest row alone then sets the pace of an
@@ -275,6 +286,12 @@ class ModelGraphRunner:
         return self._mlp_out[:bs]
 
     # ------------------------------------------------------------------ decode
+    def _all_reduce(self, t):
+        """In-place sum of [bs, hidden] over the ranks (model_graph.py:210,219)."""
+        if self.world_size == 1:
+            return t
+        return self._reducer.all_reduce(t)
+
     def _layer(self, h, layer_idx, bs, cache_manager):
         """One transformer block on hidden state `h` [bs, hid]; returns the next hidden state
         (a view of a static buffer)."""
@@ -284,13 +301,13 @@ class ModelGraphRunner:
         block = self.model.transformer.h[layer_idx]
         qkv = self._qkv_proj(h, block, bs)
         attn_out = self._flash_attn(qkv, block, layer_idx, bs, cache_manager)
-        attn_out = pc.all_reduce(attn_out)
+        attn_out = self._all_reduce(attn_out)
         rmsnorm_residual_gemm(attn_out, h, block.ln_2.weight, self._normed[:bs],
                               self._residual[:bs], block.ln_2.eps)
         if self.fused and self.world_size == 1:
             return self._ffn(self._normed[:bs], block, bs, residual=self._residual[:bs])
         mlp_out = self._ffn(self._normed[:bs], block, bs)
-        return add_(pc.all_reduce(mlp_out), self._residual[:bs])
+        return add_(self._all_reduce(mlp_out), self._residual[:bs])
 
     def _layer_norm_fused(self, h, pend, layer_idx, bs, cache_manager):
         """Block with both norms folded into the consuming projections (bs <= 4).
@@ -310,7 +327,7 @@ class ModelGraphRunner:
                        bias=block.attn._qkv_b, workspace=ws)
             h = self._hsum[:bs]
         attn_out = self._flash_attn(self._qkv[:bs], block, layer_idx, bs, cache_manager)
-        attn_out = pc.all_reduce(attn_out)
+        attn_out = self._all_reduce(attn_out)
         wgemm_norm(attn_out, block.ln_2.weight, block.ln_2.eps, block.mlp._gu, self._swiglu_out[:bs],
                    add_r=h, sum_out=self._residual[:bs], swiglu=True, workspace=ws)
         if self.world_size == 1:
@@ -318,7 +335,7 @@ class ModelGraphRunner:
                   residual=self._residual[:bs], workspace=ws)
             return self._mlp_out[:bs], None
         wgemm(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs], workspace=ws)
-        return pc.all_reduce(self._mlp_out[:bs]), self._residual[:bs]
+        return self._all_reduce(self._mlp_out[:bs]), self._residual[:bs]
 
     def _head(self, h, bs, out=None, pend=None):
         """Final norm + LM head; `out` may be an fp32 [bs,V] tensor to get un-rounded logits."""
@@ -339,7 +356,9 @@ class ModelGraphRunner:
         """One token for each of `bs` rows; returns logits [bs, V] (a view of a static buffer).
         Allocation-free after the first call for a given bs, so it can be stream-captured."""
         h = embedding(self.model.transformer.wte.weight, input_ids, self._hidden0[:bs])
-        if self.fused and bs <= 4:
+        if self.fused and self.world_size > 1 and self._reducer.fits(bs, self.hidden_dim):
+            logits = self._decode_tp(h, bs, cache_manager)
+        elif self.fused and bs <= 4:
             pend = None
             for layer_idx in range(self.num_layers):
                 h, pend = self._layer_norm_fused(h, pend, layer_idx, bs, cache_manager)
@@ -414,6 +433,54 @@ class ModelGraphRunner:
             h = self._mlp_out[:bs]
         return wgemm(normed, self._lm_head, self._logits[:bs], workspace=ws)
 
+    def _decode_tp(self, h, bs, cache_manager):
+        """Several ranks, any batch size: each of the two reductions of a block (after the O and
+        after the down projection, core/layer/model_graph.py:210,219) is ONE launch that also adds
+        the residual and applies the RMSNorm that follows (:213, and :143 of the next block), so a
+        block is QKV, attention, O, reduce+add+norm, gate/up, down, reduce+add+norm.  With the
+        one-shot reducer the row-parallel projections leave their k-slabs in the workspace and
+        the reduction adds them on the way in."""
+        tr = self.model.transformer
+        blocks = tr.h
+        ws = self._gemm_ws
+        red = self._reducer
+        n = self.hidden_dim
+        normed = self._normed[:bs]
+        hq, hkv, d = self.num_heads, self.kv_num_heads, self.head_size
+
+        def row_parallel(x, w, residual, ln, y, var_from_rounded):
+            if red.takes_slabs:
+                ks = wgemm_slabs(x, w, ws)
+                red.addnorm(bs, n, slabs=ws, ksplit=ks, residual=residual, y=y, ln_weight=ln.weight,
+                            eps=ln.eps, normed=normed, var_from_rounded=var_from_rounded)
+            else:
+                wgemm(x, w, self._attn_out[:bs], workspace=ws)
+                red.addnorm(bs, n, partial=self._attn_out[:bs], residual=residual, y=y,
+                            ln_weight=ln.weight, eps=ln.eps, normed=normed,
+                            var_from_rounded=var_from_rounded)
+
+        rmsnorm_(h, blocks[0].ln_1.weight, normed, blocks[0].ln_1.eps)
+        for layer_idx in range(self.num_layers):
+            block = blocks[layer_idx]
+            wgemm(normed, block.attn._qkv_w, self._qkv[:bs], bias=block.attn._qkv_b, workspace=ws)
+            qkv = self._qkv[:bs]
+            k_cache, v_cache = cache_manager.get(layer_idx)
+            attn = paged_attn_decode(
+                qkv[:, :hq * d].unflatten(1, (hq, d)), qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)),
+                qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d)), k_cache, v_cache,
+                cache_manager._cache_seqlens_buffer[:bs], cache_manager._block_table_buffer[:bs],
+                self.attention._cos_pool, self.attention._sin_pool,
+                num_splits=self._splits_for(bs, cache_manager), out=self._attn[:bs],
+                workspace=self._attn_ws)
+            # residual <- bf16(sum_ranks(attn @ Wo^T) + h); normed <- rmsnorm(unrounded) * ln_2
+            row_parallel(attn.reshape(bs, -1), block.attn._o, h, block.ln_2, self._residual[:bs], False)
+            wgemm(normed, block.mlp._gu, self._swiglu_out[:bs], swiglu=True, workspace=ws)
+            # h <- bf16(sum_ranks(act @ Wd^T) + residual); normed <- rmsnorm(h) * (next ln_1 | ln_f)
+            nxt = blocks[layer_idx + 1].ln_1 if layer_idx + 1 < self.num_layers else tr.ln_f
+            row_parallel(self._swiglu_out[:bs], block.mlp._d, self._residual[:bs], nxt, self._mlp_out[:bs], True)
+            h = self._mlp_out[:bs]
+        return wgemm(normed, self._lm_head, self._logits[:bs], workspace=ws)
+
     def greedy_ids(self, logits: torch.Tensor):
         """Row-wise argmax of `logits` if they are what the last decode returned (then it is already
         there), else None."""
@@ -426,7 +493,14 @@ class ModelGraphRunner:
         by the captured kernels at replay time, so their contents may change between replays."""
         if self._is_graph_ready:
             return
-        use_torch_graph = self.world_size > 1  # collectives are captured through torch's RCCL hooks
+        # torch.distributed collectives are captured through torch's RCCL hooks; the one-shot
+        # reducer is an ordinary kernel of the library
+        use_torch_graph = self.world_size > 1 and not getattr(self._reducer, "takes_slabs", False)
+        if use_torch_graph and pc.host_side_backend():
+            # a host all-reduce (gloo rehearsal) cannot be part of a graph: every rank decodes eagerly
+            logger.warning("host-side all-reduce backend: decode steps are not captured")
+            self._is_graph_ready = True
+            return
         for bs in batch_sizes:
             if bs > self.max_bs:
                 continue
@@ -445,7 +519,7 @@ class ModelGraphRunner:
         self._is_graph_ready = True
 
     def _capture_one(self, bs, cache_manager, warmup, use_torch_graph):
-        """One decode step for `bs` rows as a replayable graph (None when it cannot be captured)."""
+        """One decode step for `bs` rows as a replayable graph."""
         g = None
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
@@ -456,15 +530,11 @@ class ModelGraphRunner:
                 self.decode(self._input_ids[:bs], bs, cache_manager)
             side.synchronize()
             if use_torch_graph:
-                try:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=side):
-                        self.decode(self._input_ids[:bs], bs, cache_manager)
-                except Exception as e:  # collective not capturable here: run this bs eagerly
-                    logger.warning("graph capture with collectives failed for bs=%d (%r); "
-                                   "decode will launch eagerly", bs, e)
-                    torch.cuda.synchronize()
-                    g = None
+                # a failure here is raised, never swallowed: ranks that captured and ranks that did
+                # not would otherwise issue different sequences of collectives
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    self.decode(self._input_ids[:bs], bs, cache_manager)
             else:
                 import ctypes
                 nv.check("mv_graph_begin_capture", nv.lib().mv_graph_begin_capture(side.cuda_stream))

@@ -10,6 +10,7 @@ import torch.distributed as dist
 
 class _State:
     group = None
+    reducer = None
 
 
 _st = _State()
@@ -50,6 +51,14 @@ def rank0():
     return get_rank() == 0
 
 
+def host_side_backend():
+    """True when the process group reduces on the host (gloo): such collectives cannot be captured
+    into a device graph."""
+    if not dist.is_initialized():
+        return False
+    return dist.get_backend(get_group() or dist.group.WORLD) == "gloo"
+
+
 def all_reduce(input_):
     """In-place SUM over the tensor-parallel ranks on the current stream; returns its argument."""
     if get_world_size() == 1:
@@ -64,6 +73,55 @@ def all_reduce(input_):
         return input_
     dist.all_reduce(input_, group=group)
     return input_
+
+
+def tensor_parallel_reducer(max_rows: int, max_n: int):
+    """The object that sums the decode step's [bs, hidden] partials over the ranks and applies the
+    add + RMSNorm that follows (kernel/allreduce.py).  With every rank on a GPU of one node this is
+    the one-shot all-reduce over mapped peer buffers, unless MVLLM_ALLREDUCE=dist asks for
+    torch.distributed; whichever is chosen, all ranks choose the same (they vote).  One per process."""
+    from ..kernel.allreduce import MAX_N, MAX_ROWS, DistAllReduce, IpcAllReduce
+
+    world = get_world_size()
+    assert world > 1, "a single rank has nothing to reduce"
+    red = _st.reducer
+    if red is not None and red.fits(max_rows, max_n):
+        return red
+    if red is not None:
+        red.close()
+    group = get_group() or dist.group.WORLD
+    comm, ok = None, 0
+    want_ipc = (os.environ.get("MVLLM_ALLREDUCE", "ipc") != "dist" and torch.cuda.is_available()
+                and world <= 8 and max_rows <= MAX_ROWS and max_n <= MAX_N and max_n % 8 == 0)
+
+    # Every rank takes part in both exchanges whatever happened to it locally, so that a failure on
+    # one rank cannot leave the others waiting in a collective.
+    log = __import__("logging").getLogger(__name__)
+    handle = b""
+    if want_ipc:
+        try:
+            comm = IpcAllReduce(get_rank(), world, max_rows, max_n)
+            handle = comm.handle()
+        except Exception as e:
+            log.warning("one-shot all-reduce: no exchange buffer on rank %d: %r", get_rank(), e)
+            comm = None
+    handles = [None] * world
+    dist.all_gather_object(handles, handle, group=group)
+    if comm is not None and all(handles):
+        try:
+            comm.connect(handles)
+            ok = 1
+        except Exception as e:
+            log.warning("one-shot all-reduce: rank %d cannot map its peers: %r", get_rank(), e)
+    votes = [None] * world
+    dist.all_gather_object(votes, ok, group=group)
+    if all(v == 1 for v in votes):
+        _st.reducer = comm
+    else:
+        if comm is not None:
+            comm.close()
+        _st.reducer = DistAllReduce(all_reduce)
+    return _st.reducer
 
 
 def barrier():

@@ -825,17 +825,21 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
                       int k, void* workspace, size_t workspace_bytes, int flags,
                       mv_stream_t stream, const void* post_ln_w = nullptr, float post_eps = 0.f,
                       void* post_out = nullptr, int64_t ld_post = 0, int post_var_from_rounded = 0) {
-    if (!x || !w_tiles || !y || m <= 0 || n <= 0 || k <= 0) return MV_ERR_INVALID_ARG;
+    const bool slabs_only = (flags & MV_GEMM_SLABS) != 0;
+    if (!x || !w_tiles || (!y && !slabs_only) || m <= 0 || n <= 0 || k <= 0) return MV_ERR_INVALID_ARG;
     if (m > 64 || (n % 16) != 0 || (k % 32) != 0) return MV_ERR_UNSUPPORTED;
     if (!aligned16(x) || !aligned16(w_tiles) || (ldx % 8) != 0 || ldx < k) return MV_ERR_INVALID_ARG;
     const bool sw = (flags & MV_GEMM_SWIGLU) != 0, of32 = (flags & MV_GEMM_OUT_F32) != 0;
     if (sw && (bias || residual || of32)) return MV_ERR_UNSUPPORTED;
     if (of32 && (bias || residual)) return MV_ERR_UNSUPPORTED;
+    if (slabs_only && (sw || of32 || bias || residual || post_ln_w)) return MV_ERR_UNSUPPORTED;
     const int ncols = sw ? n / 2 : n;
-    if (ldy < ncols) return MV_ERR_INVALID_ARG;
-    if (!of32 && ((reinterpret_cast<uintptr_t>(y) & 7) != 0 || (ldy % 4) != 0))
-        return MV_ERR_INVALID_ARG;
-    if (of32 && (!aligned16(y) || (ldy % 4) != 0)) return MV_ERR_INVALID_ARG;
+    if (!slabs_only) {
+        if (ldy < ncols) return MV_ERR_INVALID_ARG;
+        if (!of32 && ((reinterpret_cast<uintptr_t>(y) & 7) != 0 || (ldy % 4) != 0))
+            return MV_ERR_INVALID_ARG;
+        if (of32 && (!aligned16(y) || (ldy % 4) != 0)) return MV_ERR_INVALID_ARG;
+    }
     if (residual && ld_res < n) return MV_ERR_INVALID_ARG;
     if (prologue != kProNone) {
         if (!aligned16(ln_w)) return MV_ERR_INVALID_ARG;
@@ -874,7 +878,12 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     a.ld_post = ld_post;
     a.post_eps = post_eps;
     a.post_var_from_rounded = post_var_from_rounded;
-    if (post_ln_w) {
+    if (slabs_only) {
+        // the caller's next kernel adds the slabs (one slab when the planner would not split)
+        const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
+        if (!workspace || workspace_bytes < need || !aligned16(workspace)) return MV_ERR_WORKSPACE;
+        a.partial = (float*)workspace;
+    } else if (post_ln_w) {
         // the norm lives in the slab reduction, so the product always goes through slabs (one
         // slab when the planner would not split)
         if (sw || of32 || (n % 8) != 0 || n > 8 * 256 * kPostChunks) return MV_ERR_UNSUPPORTED;
@@ -936,7 +945,7 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
             else rc = sg == 4 ? launch_mfma<4, 4>(a, grid, s) : sg == 2 ? launch_mfma<4, 2>(a, grid, s) : launch_mfma<4, 1>(a, grid, s);
         }
     }
-    if (rc != MV_OK) return rc;
+    if (rc != MV_OK || slabs_only) return rc;
     if (post_ln_w) {
         hipLaunchKernelGGL(wgemm_finalize_norm_kernel, dim3(m), dim3(256), 0, s, a);
         rc = check_launch();
@@ -995,6 +1004,11 @@ int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
     return mv::wgemm_impl(x, ldx, nullptr, 0, nullptr, 0.f, nullptr, 0, mv::kProNone, 0, w_tiles, bias,
                           residual, ld_res, y, ldy, m, n, k, workspace, workspace_bytes, flags,
                           stream);
+}
+
+int mv_wgemm_slab_count(int m, int n, int k) {
+    if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
+    return mv::pick_ksplit(m, n / 16, k / 32);
 }
 
 size_t mv_wgemm_postnorm_workspace_bytes(int m, int n, int k) {

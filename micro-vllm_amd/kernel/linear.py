@@ -107,6 +107,24 @@ def wgemm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
     return out
 
 
+def wgemm_slabs(x: torch.Tensor, w: StreamedWeight, workspace: torch.Tensor) -> int:
+    """x @ W^T left in `workspace` as fp32 slabs [slab][M][N] (their sum, in slab order, is the
+    product); returns the slab count.  For row-parallel projections whose output goes straight into
+    the tensor-parallel reduction (`IpcAllReduce.addnorm`), which adds the slabs itself."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    m, k = x.shape
+    assert k == w.k and not w.swiglu
+    L = nv.lib()
+    need = L.mv_wgemm_postnorm_workspace_bytes(m, w.n, k)
+    assert workspace is not None and workspace.numel() * workspace.element_size() >= need
+    ldx = x.stride(0) if m > 1 else max(k, x.stride(0))
+    nv.check("mv_wgemm", L.mv_wgemm(
+        x.data_ptr(), ldx, w.tiles.data_ptr(), None, None, 0, None, 0, m, w.n, k,
+        workspace.data_ptr(), workspace.numel() * workspace.element_size(), nv.MV_GEMM_SLABS,
+        nv.stream_ptr()))
+    return L.mv_wgemm_slab_count(m, w.n, k)
+
+
 def wgemm_postnorm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor, ln_weight: torch.Tensor,
                    eps: float, normed: torch.Tensor, bias: Optional[torch.Tensor] = None,
                    residual: Optional[torch.Tensor] = None, var_from_rounded: bool = False,
