@@ -70,8 +70,10 @@ class RefRunner:
         v = qkv[..., (hq + hkv) * D:].reshape(*lead, hkv, D)
         return q, k, v
 
-    def decode_layer(self, h, li, caches, seqlens, block_table):
-        """One block of model_graph.py:202-219 on hidden state h [bs, hid] bf16."""
+    def decode_layer(self, h, li, caches, seqlens, block_table, parts_out=None):
+        """One block of model_graph.py:202-219 on hidden state h [bs, hid] bf16.  `parts_out` (a
+        dict) receives what each rank holds before the two all-reduces and their sums:
+        "o" / "mlp" = lists of per-rank partials, "o_sum" / "mlp_sum" = the reduced tensors."""
         block = self.model.transformer.h[li]
         bs = h.shape[0]
         normed = rmsnorm_ref(h, block.ln_1.weight, block.ln_1.eps)                 # :143
@@ -86,13 +88,18 @@ class RefRunner:
                 p_bf16=self.p_bf16).squeeze(1)
             parts.append(linear_ref(attn.reshape(bs, -1), w["o"]))                 # :171
         attn_out = self._allreduce(parts)                                          # :210
+        if parts_out is not None:
+            parts_out["o"], parts_out["o_sum"] = parts, attn_out
         normed, residual = rmsnorm_residual_ref(attn_out, h, block.ln_2.weight, block.ln_2.eps)  # :213
         parts = []
         for sh in self.shards:
             w = sh.layers[li]
             gu = linear_ref(normed, w["gu"])                                       # :183
             parts.append(linear_ref(swiglu_ref(gu), w["d"]))                       # :184-185
-        return (self._allreduce(parts).float() + residual.float()).to(BF16)        # :219
+        mlp_out = self._allreduce(parts)
+        if parts_out is not None:
+            parts_out["mlp"], parts_out["mlp_sum"] = parts, mlp_out
+        return (mlp_out.float() + residual.float()).to(BF16)                       # :219
 
     def head(self, h, fp32=False):
         """model_graph.py:222-223; fp32=True returns the logits before their bf16 rounding."""
@@ -102,15 +109,20 @@ class RefRunner:
             return hn.float() @ self.lm_head.float().t()
         return linear_ref(hn, self.lm_head)
 
-    def decode(self, input_ids, caches, seqlens, block_table, trace=None):
+    def decode(self, input_ids, caches, seqlens, block_table, trace=None, parts_trace=None):
         """model_graph.py:192-223.  caches[r] = (k_caches, v_caches) lists per layer for rank r;
         seqlens int32 [bs]; block_table int32 [bs, max_blocks].  Returns logits [bs,V] bf16.
-        `trace` (a list) receives the hidden state entering each layer and the final one."""
+        `trace` (a list) receives the hidden state entering each layer and the final one;
+        `parts_trace` (a list) one `parts_out` dict of decode_layer per layer."""
         h = self.model.transformer.wte.weight[input_ids]                           # :196
         for li in range(len(self.model.transformer.h)):
             if trace is not None:
                 trace.append(h)
-            h = self.decode_layer(h, li, caches, seqlens, block_table)
+            po = None
+            if parts_trace is not None:
+                po = {}
+                parts_trace.append(po)
+            h = self.decode_layer(h, li, caches, seqlens, block_table, parts_out=po)
         if trace is not None:
             trace.append(h)
         return self.head(h)

@@ -24,7 +24,8 @@ class Tok:
         return " ".join(str(i) for i in ids)
 
 
-def _oracle_generate(cfg, cpu_model, tok, prompts, max_new, n_blocks, max_tokens, max_bs):
+def _oracle_generate(cfg, cpu_model, tok, prompts, max_new, n_blocks, max_tokens, max_bs,
+                     graph_sizes=(1, 2, 4, 8)):
     """The same policy by hand: one prefill batch per scheduler decision, then decode groups."""
     from micro_vllm_amd.core.scheduler import Scheduler
     from micro_vllm_amd.core.sequence import Sequence
@@ -33,7 +34,7 @@ def _oracle_generate(cfg, cpu_model, tok, prompts, max_new, n_blocks, max_tokens
     cache = RefKVCache(n_blocks, 256, cfg.num_hidden_layers, cfg.num_key_value_heads, cfg.head_dim,
                        max_tokens=max_tokens, max_batch_size=max_bs, strict_reference=False)
     sch = Scheduler(max_bs, 2048, tok, prefill_timeout=0.0)
-    sch.batch_sizes = [b for b in (1, 2, 4, 8) if b <= max_bs]
+    sch.batch_sizes = [b for b in graph_sizes if b <= max_bs]
     seqs = [Sequence(i, p, tok, max_new) for i, p in enumerate(prompts)]
     for s in seqs:
         sch.add_request(s)

@@ -109,6 +109,97 @@ def test_llama3_8b_dimensions_decode_step(mv, bs):
     del kv_before
 
 
+@pytest.mark.parametrize("bs", [2, 8])
+def test_llama3_8b_dimensions_every_stage_on_identical_inputs(mv, bs):
+    """The path's stated 1e-3 at the headline widths, in the form in which it is defined: every
+    STAGE of a block (norm, QKV projection, RoPE + append + paged attention, O projection, add + norm,
+    gate/up projection + SwiGLU, down projection + residual) gets the ORACLE's input, and its output is
+    held to 1e-3 plus one bf16 unit in the last place (both sides round to bf16); the LM head on its
+    un-rounded fp32 logits to 1e-3 absolute.
+
+    Why per stage and not per block at these widths: with random weights the first block turns a
+    residual stream of |x| ~ 0.04 into one of |x| ~ 2, and single-unit rounding flips multiply on the
+    way - measured on MI355X: 0.1 % of the attention outputs differ by one unit, 1.6 % of the residual
+    sum, 28 % of the SwiGLU outputs, and the block output then differs by 3.7e-3 on average although
+    every stage, fed identical inputs, is within a unit.  The whole block is therefore compared on
+    average against how far the oracle moves from ITSELF when one legitimate choice changes."""
+    from micro_vllm_amd.core.paged_attention import paged_attn_decode
+    from micro_vllm_amd.kernel.linear import wgemm
+    from micro_vllm_amd.kernel.rmsnorm_add import rmsnorm_
+    from micro_vllm_amd.kernel.rmsnorm_residual import rmsnorm_residual_gemm
+    from oracle.ref_attention import flash_attn_with_kvcache_ref
+    from oracle.ref_ops import BF16, linear_ref, rmsnorm_ref, rmsnorm_residual_ref, swiglu_ref
+
+    cfg, runner, mgr, ref, ref_cache, lens = _build(bs)
+    sids = list(range(bs))
+    ids = torch.randint(0, cfg.vocab_size, (bs,), generator=torch.Generator().manual_seed(40 + bs))
+    for sid in sids:
+        mgr.append(sid)
+        ref_cache.append(sid)
+    pos = [L + 1 for L in lens]
+    bt, sl = mgr.cache_batch_data(sids, pos)
+    rbt, rsl = ref_cache.cache_batch_data(sids, pos)
+    hq, hkv, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    dev = lambda t: t.to(DEV).contiguous()
+    empty = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=DEV)
+    ws = runner._gemm_ws
+    h = ref.model.transformer.wte.weight[ids]
+    alt = RefRunner(ref.model, D, world=1, max_blocks=ref_cache.max_seq_blocks, p_bf16=True)
+    for li in range(2):
+        blk, gblk, w = ref.model.transformer.h[li], runner.model.transformer.h[li], ref.shards[0].layers[li]
+        what = f"8B widths bs={bs} block {li}: "
+        normed = rmsnorm_ref(h, blk.ln_1.weight, blk.ln_1.eps)
+        got = rmsnorm_(dev(h), gblk.ln_1.weight, empty(bs, cfg.hidden_size), blk.ln_1.eps)
+        assert_close_bf16(got, normed, atol=1e-3, rtol=2 ** -7, what=what + "norm")
+        qkv = linear_ref(normed, w["qkv"], w["qkv_b"])
+        got = wgemm(dev(normed), gblk.attn._qkv_w, empty(bs, qkv.shape[1]), bias=gblk.attn._qkv_b, workspace=ws)
+        assert_close_bf16(got, qkv, atol=1e-3, rtol=2 ** -7, what=what + "qkv")
+        q, k, v = ref._split_qkv(qkv, (bs,))
+        kc_before = ref_cache.k_caches[li].clone()
+        attn = flash_attn_with_kvcache_ref(q.unsqueeze(1), ref_cache.k_caches[li], ref_cache.v_caches[li],
+                                           k.unsqueeze(1), v.unsqueeze(1), ref.cos, ref.sin, rsl, rbt,
+                                           causal=True, p_bf16=False).squeeze(1)
+        kc, vc = mgr.get(li)
+        got = paged_attn_decode(dev(q), dev(k), dev(v), kc, vc, sl, bt, runner.attention._cos_pool,
+                                runner.attention._sin_pool)
+        assert_close_bf16(got, attn, atol=1e-5, rtol=2 ** -7, what=what + "attention")
+        assert torch.equal(kc.cpu(), ref_cache.k_caches[li]) and torch.equal(vc.cpu(), ref_cache.v_caches[li])
+        assert not torch.equal(kc_before, ref_cache.k_caches[li])                # the append happened
+        o = linear_ref(attn.reshape(bs, -1), w["o"])
+        got = wgemm(dev(attn.reshape(bs, -1)), gblk.attn._o, empty(bs, cfg.hidden_size), workspace=ws)
+        assert_close_bf16(got, o, atol=1e-3, rtol=2 ** -7, what=what + "o")
+        normed2, residual = rmsnorm_residual_ref(o, h, blk.ln_2.weight, blk.ln_2.eps)
+        gn, gr = rmsnorm_residual_gemm(dev(o), dev(h), gblk.ln_2.weight, empty(bs, cfg.hidden_size),
+                                       empty(bs, cfg.hidden_size), blk.ln_2.eps)
+        assert torch.equal(gr.cpu(), residual), what + "residual sum"
+        assert_close_bf16(gn, normed2, atol=1e-3, rtol=2 ** -7, what=what + "add+norm")
+        act = swiglu_ref(linear_ref(normed2, w["gu"]))
+        got = wgemm(dev(normed2), gblk.mlp._gu, empty(bs, act.shape[1]), swiglu=True, workspace=ws)
+        assert_close_bf16(got, act, atol=1e-3, rtol=2 ** -7, what=what + "gate/up + swiglu")
+        mlp = linear_ref(act, w["d"])
+        out = (mlp.float() + residual.float()).to(BF16)
+        got = wgemm(dev(act), gblk.mlp._d, empty(bs, cfg.hidden_size), residual=dev(residual), workspace=ws)
+        assert_close_bf16(got, out, atol=1e-3, rtol=2 ** -7, what=what + "down + residual")
+        # the block as the runner fuses it, on the same block input: on average within a small multiple
+        # of the oracle's distance from itself with P rounded to bf16 before P.V
+        runner._hidden0[:bs] = dev(h)
+        fused_out = runner._layer(runner._hidden0[:bs], li, bs, mgr).float().cpu()
+        alt_cache_k = [c.clone() for c in ref_cache.k_caches]
+        alt_cache_v = [c.clone() for c in ref_cache.v_caches]
+        alt_out = alt.decode_layer(h, li, [(alt_cache_k, alt_cache_v)], rsl, rbt).float()
+        floor = (alt_out - out.float()).abs().mean().item()
+        assert (fused_out - out.float()).abs().mean().item() <= 4 * floor + 1e-3, (floor, li)
+        h = out
+    runner._hidden0[:bs] = dev(h)
+    f32 = torch.empty(bs, cfg.vocab_size, dtype=torch.float32, device=DEV)
+    runner._head(runner._hidden0[:bs], bs, out=f32)
+    want32 = ref.head(h, fp32=True)
+    err = (f32.cpu() - want32).abs().max().item()
+    assert err <= 1e-3, err
+    logits = runner._head(runner._hidden0[:bs], bs)
+    assert_close_bf16(logits, ref.head(h), atol=1e-3, rtol=2 ** -7, what="bf16 logits")
+
+
 def test_llama3_8b_dimensions_fused_equals_separate_kernels(mv):
     """Norm-in-prologue / epilogue-fused step against the step made of the reference's separate ops."""
     outs = []

@@ -1,7 +1,9 @@
-"""The decode runner's tensor-parallel wiring with two ranks sharing the one GPU of the test box:
-HIP kernels compute each rank's shard, gloo carries the two all-reduces per layer (RCCL needs one
-GPU per rank).  Checks slicing, the deferred residual add in the next QKV prologue, and that both
-ranks end with the oracle's logits."""
+"""The decode runner's tensor-parallel wiring with 2 and 4 ranks sharing the one GPU of the test box:
+HIP kernels compute each rank's shard; the two reductions per block go through the one-shot
+all-reduce over IPC-mapped buffers (the path ranks on separate GPUs take: mv_allreduce_addnorm, slabs
+in, add + norm fused) or, with MVLLM_ALLREDUCE=dist, through torch.distributed (gloo here, RCCL needs
+one GPU per rank) followed by the norm kernels.  Checks slicing, the reduction, the captured step,
+and that all ranks end with the oracle's logits."""
 import os
 import socket
 import sys
@@ -13,6 +15,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 pytestmark = pytest.mark.gpu
+LENS = [3, 300, 40, 255, 17, 64, 500, 129, 9, 31, 257, 100, 7, 450, 64, 200]
 
 
 def _free_port():
@@ -23,33 +26,37 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fused, bs, out_q):
+def _worker(rank, world, port, shape, fused, bs, mode, graph, out_q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
-                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVLLM_DIST_BACKEND="gloo")
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MVLLM_DIST_BACKEND="gloo",
+                      MVLLM_ALLREDUCE=mode, MVLLM_ALLREDUCE_TIMEOUT_MS="20000")
     sys.path.insert(0, ROOT)
     import micro_vllm_amd  # noqa: F401
     from micro_vllm_amd.core import parallel_config as pc
     from micro_vllm_amd.core.cache_manager import KVCacheManager
     from micro_vllm_amd.core.layer.model_graph import ModelGraphRunner
+    from micro_vllm_amd.kernel.allreduce import IpcAllReduce
     from micro_vllm_amd.models import SHAPES, build_synthetic_model
 
     torch.cuda.set_device(0)
     pc.setup()
     dev = "cuda"
-    cfg = SHAPES["tiny-gqa"]
+    cfg = SHAPES[shape]
     model = build_synthetic_model(cfg, "cpu", seed=1234, qkv_bias=True).to(dev)
     hkv = cfg.num_key_value_heads // world
+    n_pages = 2 * bs + 2
     runner = ModelGraphRunner(model, cfg.num_hidden_layers, cfg.num_attention_heads // world,
                               cfg.head_dim, hkv, cfg.hidden_size, cfg.intermediate_size // world, dev,
-                              max_batch_size=8, fused=fused)
+                              max_batch_size=16, fused=fused)
     assert runner.world_size == world and runner.rank == rank
-    mgr = KVCacheManager(8, 256, cfg.num_hidden_layers, hkv, cfg.head_dim, dtype=torch.bfloat16,
-                         device=dev, max_tokens=1024, max_batch_size=8)
+    assert isinstance(runner._reducer, IpcAllReduce) == (mode == "ipc")
+    mgr = KVCacheManager(n_pages, 256, cfg.num_hidden_layers, hkv, cfg.head_dim, dtype=torch.bfloat16,
+                         device=dev, max_tokens=1024, max_batch_size=16)
     g = torch.Generator().manual_seed(5)
-    lens = [3, 300, 40, 255, 17, 64][:bs]
+    lens = LENS[:bs]
     for li in range(cfg.num_hidden_layers):
-        fk = torch.randn(8, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
-        fv = torch.randn(8, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
+        fk = torch.randn(n_pages, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
+        fv = torch.randn(n_pages, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16)
         mgr.k_caches[li].copy_(fk[:, :, rank * hkv:(rank + 1) * hkv])
         mgr.v_caches[li].copy_(fv[:, :, rank * hkv:(rank + 1) * hkv])
     for sid, L in enumerate(lens):
@@ -59,15 +66,32 @@ def _worker(rank, world, port, fused, bs, out_q):
     ids = torch.arange(bs, dtype=torch.long) * 13 + 5
     runner._input_ids[:bs] = ids.to(dev)
     logits = runner.decode(runner._input_ids[:bs], bs, mgr).float().cpu()
+    replay_equal = None
+    if graph:
+        # the same step captured and replayed: the new key lands on the same slot with the same bits
+        runner.capture(mgr, batch_sizes=[bs])
+        assert bs in runner._graphs
+        for _ in range(3):
+            again = runner.forward(ids.to(dev), mgr, bs).float().cpu()
+        replay_equal = bool(torch.equal(again, logits))
     bt = mgr._block_table_buffer[:bs].cpu()
+    status = runner._reducer.status()
     pc.barrier()
-    out_q.put((rank, logits.numpy(), bt.numpy()))
+    out_q.put((rank, logits.numpy(), bt.numpy(), replay_equal, status))
+    runner._reducer.close()
     import torch.distributed as dist
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("fused,bs", [(True, 2), (False, 2), (True, 6)])
-def test_two_ranks_on_one_gpu_match_the_oracle(fused, bs):
+@pytest.mark.parametrize("world,shape,fused,bs,mode,graph", [
+    (2, "tiny-gqa", True, 2, "ipc", True),      # bs <= 4: the dot-product projections leave the slabs
+    (2, "tiny-gqa", True, 16, "ipc", True),     # the configuration's batch size, matrix-core projections
+    (4, "tiny-mha", True, 6, "ipc", True),
+    (2, "tiny-gqa", False, 2, "ipc", False),    # the reference's separate ops with the plain one-shot sum
+    (2, "tiny-gqa", True, 6, "dist", False),    # torch.distributed + norm kernels behind the same interface
+    (2, "tiny-gqa", False, 2, "dist", False),
+])
+def test_ranks_on_one_gpu_match_the_oracle(world, shape, fused, bs, mode, graph):
     sys.path.insert(0, ROOT)
     from micro_vllm_amd.models import SHAPES, build_synthetic_model
     from oracle.ref_model import RefRunner
@@ -75,33 +99,39 @@ def test_two_ranks_on_one_gpu_match_the_oracle(fused, bs):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, fused, bs, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, fused, bs, mode, graph, q))
+             for r in range(world)]
     for p in procs:
         p.start()
     got = {}
-    for _ in range(2):
-        r, lg, bt = q.get(timeout=300)
+    for _ in range(world):
+        r, lg, bt, replay_equal, status = q.get(timeout=300)
         got[r] = (torch.from_numpy(lg), torch.from_numpy(bt))
+        assert status == 0, "a rank timed out waiting for a peer"
+        if graph:
+            assert replay_equal, f"rank {r}: captured step differs from the eager one"
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert torch.equal(got[0][0], got[1][0]), "ranks disagree"
-    assert torch.equal(got[0][1], got[1][1])
+    for r in range(1, world):
+        assert torch.equal(got[0][0], got[r][0]), "ranks disagree"
+        assert torch.equal(got[0][1], got[r][1])
 
-    cfg = SHAPES["tiny-gqa"]
+    cfg = SHAPES[shape]
     model = build_synthetic_model(cfg, "cpu", seed=1234, qkv_bias=True)
     g = torch.Generator().manual_seed(5)
+    n_pages = 2 * bs + 2
     fks, fvs = [], []
     for li in range(cfg.num_hidden_layers):
-        fks.append(torch.randn(8, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16))
-        fvs.append(torch.randn(8, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16))
-    hkv = cfg.num_key_value_heads // 2
+        fks.append(torch.randn(n_pages, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16))
+        fvs.append(torch.randn(n_pages, 256, cfg.num_key_value_heads, cfg.head_dim, generator=g).to(torch.bfloat16))
+    hkv = cfg.num_key_value_heads // world
     caches = [([t[:, :, r * hkv:(r + 1) * hkv].contiguous() for t in fks],
-               [t[:, :, r * hkv:(r + 1) * hkv].contiguous() for t in fvs]) for r in range(2)]
-    lens = [3, 300, 40, 255, 17, 64][:bs]
+               [t[:, :, r * hkv:(r + 1) * hkv].contiguous() for t in fvs]) for r in range(world)]
+    lens = LENS[:bs]
     sl = torch.tensor([L + 1 for L in lens], dtype=torch.int32)
     ids = torch.arange(bs, dtype=torch.long) * 13 + 5
-    want = RefRunner(model, cfg.head_dim, world=2).decode(ids, caches, sl, got[0][1]).float()
+    want = RefRunner(model, cfg.head_dim, world=world).decode(ids, caches, sl, got[0][1]).float()
     err = (got[0][0] - want).abs()
     tol = 2.0 ** -7 * float(want.abs().max()) + 2 ** -7 * want.abs()
     assert bool((err <= tol).all()), f"max err {err.max().item()}"

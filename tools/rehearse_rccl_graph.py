@@ -29,7 +29,6 @@ def counted(t, *a, **k):
 
 
 dist.all_reduce = counted
-pc.get_world_size = lambda: 2           # the runner shards for two ranks and takes the TP > 1 path
 shape = sys.argv[1] if len(sys.argv) > 1 else "tiny-d128"
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 cfg = SHAPES[shape]
@@ -38,8 +37,17 @@ model = build_synthetic_model(cfg, "cuda", seed=1, num_layers=layers)
 hq, hkv = cfg.num_attention_heads // 2, cfg.num_key_value_heads // 2
 mgr = KVCacheManager(n_blocks=4 * bs + 4, block_size=256, n_layers=layers, n_heads=hkv, head_size=cfg.head_dim,
                      dtype=torch.bfloat16, device="cuda", max_tokens=1024, max_batch_size=bs)
+from micro_vllm_amd.kernel.allreduce import DistAllReduce
+
+
+def rccl_sum(t):                        # what pc.all_reduce does with more than one rank
+    dist.all_reduce(t, group=dist.group.WORLD)
+    return t
+
+
+# the runner shards as rank 0 of 2 and takes the several-ranks path, reducing through RCCL
 runner = ModelGraphRunner(model, layers, hq, cfg.head_dim, hkv, cfg.hidden_size, cfg.intermediate_size // 2,
-                          "cuda", max_batch_size=bs)
+                          "cuda", max_batch_size=bs, reducer=DistAllReduce(rccl_sum), tp_rank=0, tp_world=2)
 assert runner.world_size == 2
 lens = [300 + 17 * i for i in range(bs)]
 for i, L in enumerate(lens):
