@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--layers", type=int, default=0, help="build only this many layers (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the prefill leg of the report")
+    ap.add_argument("--no-bs32", action="store_true", help="skip the batch-32 legs of the report")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tail-steps", type=int, default=50,
                     help="steps timed one by one AFTER the timed region, for the median / p99 step")
@@ -137,49 +138,173 @@ def prefill_leg(args, cfg, layers, runner, dev, reps=3):
             "logits": "last position only (what the engine samples from)"}
 
 
-def gemm_only_timing(runner, bs, layers, reps=20):
-    """Average duration of the projection kernels of one decode step, launched back to back
-    (hipGraph of exactly those launches) and bracketed by HIP events on the launch stream."""
+def projection_timing(runner, bs, layers, reps=20):
+    """Average duration of the projection launches of one decode step, issued exactly as the step
+    issues them - with the norm prologues (bs <= 4) or the slab reduction + norm launches (bs > 4),
+    bias / SwiGLU / residual epilogues - back to back as one hipGraph, bracketed by HIP events on
+    the stream the graph is launched on.  Attention, embedding and the token pick are left out, so the
+    figure is the dominant kernel's own; the ~0.2 us between graph nodes is inside it."""
     import ctypes
     from micro_vllm_amd import _native as nv
-    from micro_vllm_amd.kernel.linear import wgemm
+    from micro_vllm_amd.kernel.linear import wgemm, wgemm_norm, wgemm_postnorm
 
     tr = runner.model.transformer
+    ws = runner._gemm_ws
+    h, normed, resid = runner._hidden0[:bs], runner._normed[:bs], runner._residual[:bs]
+    attn = runner._attn[:bs].reshape(bs, -1)
 
     def one_pass():
+        n = 0
         for li in range(layers):
             b = tr.h[li]
-            wgemm(runner._normed[:bs], b.attn._qkv_w, runner._qkv[:bs], bias=b.attn._qkv_b,
-                  workspace=runner._gemm_ws)
-            wgemm(runner._attn[:bs].reshape(bs, -1), b.attn._o, runner._attn_out[:bs],
-                  workspace=runner._gemm_ws)
-            wgemm(runner._normed[:bs], b.mlp._gu, runner._swiglu_out[:bs], swiglu=True,
-                  workspace=runner._gemm_ws)
-            wgemm(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs],
-                  residual=runner._residual[:bs], workspace=runner._gemm_ws)
-        wgemm(runner._normed[:bs], runner._lm_head, runner._logits[:bs], workspace=runner._gemm_ws)
+            if bs <= 4:     # ModelGraphRunner._layer_norm_fused
+                wgemm_norm(h, b.ln_1.weight, b.ln_1.eps, b.attn._qkv_w, runner._qkv[:bs], bias=b.attn._qkv_b,
+                           workspace=ws)
+                wgemm(attn, b.attn._o, runner._attn_out[:bs], workspace=ws)
+                wgemm_norm(runner._attn_out[:bs], b.ln_2.weight, b.ln_2.eps, b.mlp._gu, runner._swiglu_out[:bs],
+                           add_r=h, sum_out=resid, swiglu=True, workspace=ws)
+                wgemm(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs], residual=resid, workspace=ws)
+            else:           # ModelGraphRunner._decode_batched
+                wgemm(normed, b.attn._qkv_w, runner._qkv[:bs], bias=b.attn._qkv_b, workspace=ws)
+                wgemm_postnorm(attn, b.attn._o, resid, b.ln_2.weight, b.ln_2.eps, normed, residual=h, workspace=ws)
+                wgemm(normed, b.mlp._gu, runner._swiglu_out[:bs], swiglu=True, workspace=ws)
+                wgemm_postnorm(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs], b.ln_1.weight, b.ln_1.eps,
+                               normed, residual=resid, var_from_rounded=True, workspace=ws)
+            n += 4
+        if bs <= 4:
+            wgemm_norm(h, tr.ln_f.weight, tr.ln_f.eps, runner._lm_head, runner._logits[:bs], workspace=ws)
+        else:
+            wgemm(normed, runner._lm_head, runner._logits[:bs], workspace=ws)
+        return n + 1
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        one_pass()
+        n_launch = one_pass()
         side.synchronize()
         nv.check("begin", nv.lib().mv_graph_begin_capture(side.cuda_stream))
         one_pass()
-        h = ctypes.c_void_p()
-        nv.check("end", nv.lib().mv_graph_end_capture(side.cuda_stream, ctypes.byref(h)))
+        h_ = ctypes.c_void_p()
+        nv.check("end", nv.lib().mv_graph_end_capture(side.cuda_stream, ctypes.byref(h_)))
         for _ in range(3):
-            nv.lib().mv_graph_launch(h, side.cuda_stream)
+            nv.lib().mv_graph_launch(h_, side.cuda_stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(side)
         for _ in range(reps):
-            nv.lib().mv_graph_launch(h, side.cuda_stream)
+            nv.lib().mv_graph_launch(h_, side.cuda_stream)
         e1.record(side)
         side.synchronize()
-        nv.lib().mv_graph_destroy(h)
+        nv.lib().mv_graph_destroy(h_)
     torch.cuda.current_stream().wait_stream(side)
-    n_launch = 4 * layers + 1
     return e0.elapsed_time(e1) * 1e-3 / (reps * n_launch), n_launch
+
+
+def roofline_block(runner, cfg, bs, layers, world, weight_bytes, step_bytes, step_seconds):
+    """The `roofline` object of the bench line: the dominant kernel's achieved bytes per second from
+    the in-run graph timing, the whole step's next to it, and the HBM traffic per launch from the
+    committed counter passes (rocprofv3 --pmc cannot run inside this process), labelled with the file
+    it comes from."""
+    t_k, n_launch = projection_timing(runner, bs, layers)
+    per_launch = weight_bytes / n_launch
+    ach = per_launch / t_k / 1e9
+    kname = "wgemm_dot_kernel" if bs <= 4 else "wgemm_mfma_kernel"
+    traffic, source = None, None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            d = json.load(open(tf))
+            key = f"{kname}:{cfg.name}:bs{bs}:tp{world}"
+            traffic = d.get(key)
+            if traffic is not None:
+                source = (d.get(key + ":detail") or {}).get(
+                    "source", "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/pmc_traffic.py)")
+        except Exception:
+            traffic = None
+    return {
+        "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": source,
+        "kernel": kname,
+        "bytes_per_launch": int(per_launch),
+        "avg_launch_us": round(t_k * 1e6, 3),
+        "launches_per_step": n_launch,
+        "timing": "HIP events around a hipGraph of the step's projection launches as the step issues them "
+                  "(norm prologues / slab-reduction norms and epilogues included), measured in this run",
+        "step_frac": round(step_bytes / step_seconds / 1e9 / HBM_PEAK_GBS, 4),
+    }
+
+
+def batch_leg(args, cfg, layers, model, dev, bs, ragged, steps=60, warmup=10):
+    """Decode at another batch size on the same weights, inside the same run: its own runner
+    (sharing the weight image), KV pool, captured graph, timed region and roofline object."""
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+    from micro_vllm_amd.core.layer.model_graph import ModelGraphRunner
+
+    total_tokens = args.ctx + steps + warmup + 8
+    blocks_per_seq = (total_tokens + 255) // 256 + 1
+    runner = ModelGraphRunner(model, layers, cfg.num_attention_heads, cfg.head_dim, cfg.num_key_value_heads,
+                              cfg.hidden_size, cfg.intermediate_size, dev, max_batch_size=bs,
+                              max_blocks=max(32, blocks_per_seq), release_source_weights=True)
+    mgr = KVCacheManager(bs * blocks_per_seq + 2, 256, layers, cfg.num_key_value_heads, cfg.head_dim,
+                         dtype=torch.bfloat16, device=dev, max_tokens=blocks_per_seq * 256, max_batch_size=bs)
+    order = list(mgr._free)
+    random.Random(2).shuffle(order)
+    mgr._free.clear()
+    mgr._free.extend(order)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    mgr._k_store.normal_(0.0, 1.0, generator=g)
+    mgr._v_store.normal_(0.0, 1.0, generator=g)
+    rng = random.Random(3)
+    ctxs = [rng.randint(min(256, args.ctx), args.ctx) if ragged else args.ctx for _ in range(bs)]
+    for sid in range(bs):
+        assert mgr.alloc(sid, ctxs[sid])[0], "KV pool too small"
+    runner.capture(mgr, batch_sizes=[bs])
+    seq_ids = list(range(bs))
+    ids = torch.randint(0, cfg.vocab_size, (bs,), generator=torch.Generator().manual_seed(0)).to(dev)
+
+    def step(ids, pos):
+        for sid in seq_ids:
+            mgr.append(sid)
+        mgr.cache_batch_data(seq_ids, [c + pos for c in ctxs])
+        return runner.greedy_ids(runner.forward(ids, mgr, bs))
+
+    pos = 1
+    for _ in range(warmup):
+        ids = step(ids, pos)
+        pos += 1
+    torch.cuda.synchronize()
+    pos0 = pos
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ids = step(ids, pos)
+        pos += 1
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(runner._logits[:bs].float()).all()), "non-finite logits"
+    wbytes = cfg.weight_bytes(1)
+    if layers != cfg.num_hidden_layers:
+        import dataclasses
+        wbytes = dataclasses.replace(cfg, num_hidden_layers=layers).weight_bytes(1)
+    kv_tok = cfg.kv_bytes_per_token(1) * layers // cfg.num_hidden_layers
+    mean_keys = sum(ctxs) / bs + (pos0 + pos0 + steps - 1) / 2.0 + 1.0
+    step_bytes = wbytes + bs * (mean_keys + 1.0) * kv_tok
+    out = {
+        "metric": "decode tokens/sec", "value": round(bs * steps / dt, 1), "unit": "tokens/s",
+        "batch": bs, "seq_len": args.ctx, "contexts": "uniform in [256, seq_len] (seed 3)" if ragged else "seq_len for every row",
+        "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+        "graph": bs in runner._graphs,
+        "uneven_split_graph": bs in runner._graphs_uneven and runner._rows_uneven(mgr, bs),
+        "step_algorithmic_GB": round(step_bytes / 1e9, 3),
+        "step_hbm_frac": round(step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS, 4),
+    }
+    try:
+        out["roofline"] = roofline_block(runner, cfg, bs, layers, 1, wbytes, step_bytes, dt / steps)
+    except Exception as e:
+        log(f"[bench] bs={bs} roofline measurement failed: {e!r}")
+        out["roofline"] = None
+    del runner, mgr
+    torch.cuda.empty_cache()
+    return out
 
 
 def shape_table(runner, bs, layers):
@@ -420,28 +545,20 @@ def main():
 
     if rank == 0:
         try:
-            t_k, n_launch = gemm_only_timing(runner, bs, layers)
-            per_launch = full_cfg_bytes / n_launch
-            ach = per_launch / t_k / 1e9
-            kname = "wgemm_dot_kernel" if bs <= 4 else "wgemm_mfma_kernel"
-            traffic = None
-            tf = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tf):
-                try:
-                    traffic = json.load(open(tf)).get(f"{kname}:{cfg.name}:bs{bs}:tp{world}")
-                except Exception:
-                    traffic = None
-            out["roofline"] = {
-                "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": kname,
-                "bytes_per_launch": int(per_launch),
-                "avg_launch_us": round(t_k * 1e6, 3),
-                "launches_per_step": n_launch,
-            }
+            out["roofline"] = roofline_block(runner, cfg, bs, layers, world, full_cfg_bytes, step_bytes,
+                                             dt / args.steps)
         except Exception as e:  # the headline number must still be printed
             log(f"[bench] roofline measurement failed: {e!r}")
             out["roofline"] = None
+        if world == 1 and bs == 1 and not args.no_bs32 and args.model == "llama3-8b":
+            # the other batch size the metric names, on the record of the same run
+            out["bs32"] = {}
+            for name, ragged in (("even", False), ("ragged", True)):
+                try:
+                    out["bs32"][name] = batch_leg(args, cfg, layers, runner.model, dev, 32, ragged)
+                except Exception as e:
+                    log(f"[bench] bs=32 {name} leg failed: {e!r}")
+                    out["bs32"][name] = None
         if args.shapes:
             shape_table(runner, bs, layers)
         if world == 1 and not args.no_prefill:

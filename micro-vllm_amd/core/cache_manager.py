@@ -135,6 +135,27 @@ class KVCacheManager:
               f"(blocks={blocks}, used={used}, block_size={self.block_size})")
         return -1
 
+    def clear_slots(self, seq_ids: list, positions: list):
+        """Zero the K and V rows (every layer, every kv head) at token index positions[i] of sequence
+        seq_ids[i].  Pages are recycled without being cleared, so a slot that the position numbering
+        makes attention read before anything writes it (the one right after a prompt, see
+        InferenceEngine._decode) would otherwise hold another request's keys.  Positions whose page
+        is not allocated are skipped.  Two small launches for the whole batch."""
+        pages, offs = [], []
+        for sid, pos in zip(seq_ids, positions):
+            blocks = self._blocks.get(sid)
+            if blocks is None or pos < 0 or pos // self.block_size >= len(blocks):
+                continue
+            pages.append(blocks[pos // self.block_size])
+            offs.append(pos % self.block_size)
+        if not pages:
+            return 0
+        pg = torch.tensor(pages, dtype=torch.long).to(self.device, non_blocking=True)
+        of = torch.tensor(offs, dtype=torch.long).to(self.device, non_blocking=True)
+        self._k_store[:, pg, of] = 0
+        self._v_store[:, pg, of] = 0
+        return len(pages)
+
     def put(self, seq_id: int, key: torch.Tensor, value: torch.Tensor, layer: int,
             slot_map: torch.Tensor):
         store_kvcache(key, value, self.k_caches[layer], self.v_caches[layer], slot_map,

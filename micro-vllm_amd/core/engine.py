@@ -40,7 +40,8 @@ class InferenceEngine:
                  max_prefill_tokens: int = 2048, *, model=None, tokenizer=None,
                  n_blocks: Optional[int] = None, max_tokens: int = 1024,
                  graph_batch_sizes: Optional[List[int]] = None, prefill_timeout: float = 0.02,
-                 exact_rope: bool = False, trust_remote_code: bool = False, kv_fraction: float = 0.9):
+                 exact_rope: bool = False, trust_remote_code: bool = False, kv_fraction: float = 0.9,
+                 clear_unwritten_slot: bool = True, sample_last_real_token: bool = False):
         """`max_tokens` is the longest sequence a block-table row can describe (the reference's
         KVCacheManager default, 1024, gives four columns - pass more for long contexts).
         `n_blocks`: None = the reference's 81 pages (core/engine.py:53-57), a number, or "auto" =
@@ -48,7 +49,17 @@ class InferenceEngine:
         288 GB device an 8B model leaves room for more than a million cached tokens).
         `exact_rope` builds the rotary tables from fp32 positions; the default keeps the
         reference's bf16 positions (core/paged_attention.py:50-52), which merge neighbouring
-        positions above 256 - with a trained checkpoint and long contexts pass True."""
+        positions above 256 - with a trained checkpoint and long contexts pass True.
+        `clear_unwritten_slot`: the reference's position numbering (core/sequence.py:17,42 with
+        core/engine.py:262) leaves token index S of a sequence prefilled with S (padded) tokens
+        unwritten - the first generated token lands at S + 1 - and attends to it ever after.  In
+        the reference that slot holds zeros on a fresh pool and another request's keys once pages
+        have been recycled; here it is zeroed on the sequence's first decode step, so outputs are
+        those of the reference on a fresh pool and never depend on what a page held before.  False
+        leaves the slot as it is.
+        `sample_last_real_token`: take the first generated token of a right-padded prompt from the
+        logits of its last REAL token instead of the batch's last (pad) position, which is what the
+        reference samples from (core/engine.py:233 with core/scheduler.py:157-163)."""
         setup()
         self.rank = get_rank()
         if model is None:
@@ -74,6 +85,12 @@ class InferenceEngine:
         kv_heads = getattr(cfg, "num_key_value_heads", heads)
         self.head_size = getattr(cfg, "head_dim", cfg.hidden_size // heads)
         assert heads % world == 0 and kv_heads % world == 0
+        # what the attention kernels are built for - checked before any weight moves to the device
+        if self.head_size not in (64, 128) or heads % kv_heads or heads // kv_heads not in (1, 2, 4, 8):
+            raise ValueError(
+                f"unsupported attention shape: head size {self.head_size} (supported: 64, 128), "
+                f"{heads} query heads on {kv_heads} kv heads = {heads / kv_heads:g} per kv head "
+                f"(supported: 1, 2, 4, 8)")
         self.num_heads, self.kv_num_heads = heads // world, kv_heads // world
         self.intermediate_size = cfg.intermediate_size // world
 
@@ -97,6 +114,8 @@ class InferenceEngine:
             max_tokens=max_tokens, max_batch_size=max_batch_size)
         self.scheduler = Scheduler(max_batch_size, max_prefill_tokens, tokenizer, prefill_timeout)
         self.sampler = Sampler()
+        self.clear_unwritten_slot = clear_unwritten_slot
+        self.sample_last_real_token = sample_last_real_token
 
         # The synchronous token read-back at the end of a step means a staging row is never
         # overwritten before its copy has run; two rows keep that true if a caller pipelines.
@@ -213,12 +232,23 @@ class InferenceEngine:
         temps = torch.tensor([seq.temperature for seq in batch], device=device)
         topp = torch.tensor([seq.top_p for seq in batch], device=device)
         seq_lens = [input_ids.shape[1]] * len(batch)
+        taken = []
         for seq in batch:
             ok, _ = self.cache_manager.alloc(seq.seq_id, seq_lens[0])
             if not ok:
+                # give back what this batch took so far: the caller may retry or fail the requests,
+                # the pool must not shrink either way (the reference leaks these pages)
+                for sid in taken:
+                    self.cache_manager.free(sid)
                 raise RuntimeError("OOM")
+            taken.append(seq.seq_id)
         self.cache_manager.cache_batch_data([s.seq_id for s in batch], seq_lens)
-        logits = self.prefill_runner.forward(input_ids, self.cache_manager, len(batch), last_token_only=True)
+        last = None
+        if self.sample_last_real_token:
+            # full_ids still holds the prompt as it was before the scheduler padded input_ids
+            last = [len(seq.full_ids) - len(seq.output_ids) - 1 for seq in batch]
+        logits = self.prefill_runner.forward(input_ids, self.cache_manager, len(batch), last_token_only=True,
+                                             last_token_index=last)
         if rank0():
             next_tokens = self._sample(logits[:, -1, :], temps, topp, 1000)
             for i, seq in enumerate(batch):
@@ -244,6 +274,13 @@ class InferenceEngine:
         for i, seq in enumerate(batch):
             if first[i] and self.cache_manager.append(seq.seq_id) == -1:
                 raise RuntimeError("OOM")
+        if self.clear_unwritten_slot:
+            # first decode step of a sequence (one token generated so far, by prefill): index
+            # current_position - 1 has never been written and is attended from now on
+            fresh = [seq for i, seq in enumerate(batch) if first[i] and len(seq.output_ids) == 1]
+            if fresh:
+                self.cache_manager.clear_slots([s.seq_id for s in fresh],
+                                               [s.current_position - 1 for s in fresh])
         self.cache_manager.cache_batch_data([s.seq_id for s in batch], [s.current_position for s in batch])
         # The pick (argmax, or temperature / top-k / top-p draw) is part of the captured step: the
         # runner's static per-row parameters are rewritten when the batch composition changes, the

@@ -63,10 +63,13 @@ class ModelPrefillRunner(ModelGraphRunner):
         return add_(pc.all_reduce(self._fast_mlp(normed, block.mlp._gu, block.mlp._d)), residual)
 
     def forward(self, input_ids: torch.Tensor, cache_manager, batch_size: int,
-                last_token_only: bool = False) -> torch.Tensor:
+                last_token_only: bool = False, last_token_index=None) -> torch.Tensor:
         """input_ids [B,S] (right-padded to a common S by the caller).  Returns logits [B,S,V], or
         [B,1,V] holding only the last position when `last_token_only` (what the engine samples
-        from, core/engine.py:233) - that skips S-1 of every S rows of the LM head."""
+        from, core/engine.py:233) - that skips S-1 of every S rows of the LM head.
+        `last_token_index` (B integers) returns [B,1,V] too, row b taken at position
+        last_token_index[b]: the last REAL token of a right-padded prompt instead of the pad
+        position the reference samples from."""
         B, S = input_ids.shape
         assert B == batch_size
         T = B * S
@@ -81,7 +84,12 @@ class ModelPrefillRunner(ModelGraphRunner):
         for layer_idx in range(self.num_layers):
             h = self._prefill_layer(h, layer_idx, B, S, cache_manager, cache_lens, block_table)
 
-        if last_token_only:
+        if last_token_index is not None:
+            idx = torch.as_tensor(last_token_index, dtype=torch.long).to(dev)
+            assert idx.numel() == B
+            h = h.view(B, S, self.hidden_dim)[torch.arange(B, device=dev), idx.clamp(0, S - 1)].contiguous()
+            S = 1
+        elif last_token_only:
             h = h.view(B, S, self.hidden_dim)[:, -1].contiguous()
             S = 1
         h = rmsnorm(h, tr.ln_f.weight, tr.ln_f.eps)

@@ -65,8 +65,12 @@ def paged_attn_prefill(q, k, v, k_cache, v_cache, cache_seqlens, block_table, so
     NB, page, _, _ = k_cache.shape
     # slot of every new token: page table lookup on the device (no host round trip)
     pos = cache_seqlens[:B].to(torch.long)[:, None] + torch.arange(S, device=q.device)[None, :]
-    pages = torch.gather(block_table[:B].to(torch.long), 1, pos // page)
-    slots = torch.where(pages >= 0, pages * page + pos % page, torch.full_like(pages, -1))
+    # positions past the last block-table column have no page: their tokens are dropped (slot -1),
+    # never looked up (an index past the row would fault inside gather)
+    col = pos // page
+    inside = (col < block_table.shape[1]) & (pos >= 0)
+    pages = torch.gather(block_table[:B].to(torch.long), 1, col.clamp(0, block_table.shape[1] - 1))
+    slots = torch.where(inside & (pages >= 0), pages * page + pos % page, torch.full_like(pages, -1))
     from .cache_manager import store_kvcache
     store_kvcache(k.reshape(B * S, Hkv, D).contiguous(), v.reshape(B * S, Hkv, D).contiguous(),
                   k_cache, v_cache, slots.reshape(-1).to(torch.int32), page)

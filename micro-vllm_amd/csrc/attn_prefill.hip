@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void rope_store_kernel(RopeStoreArgs a) {
         uint16_t* base = a.qkv + tok * a.row_stride + (int64_t)h * a.d;
         uint4 v1 = ld16(base + c * 8), v2 = ld16(base + (a.d >> 1) + c * 8);
         if (h < a.hq + a.hkv && a.cos) {
-            const int rp = min(pos, a.rot_max_pos - 1);
+            const int rp = min(max(pos, 0), a.rot_max_pos - 1);
             const uint4 cv = ld16(a.cos + (int64_t)rp * (a.d >> 1) + c * 8);
             const uint4 sv = ld16(a.sin + (int64_t)rp * (a.d >> 1) + c * 8);
             rope_pair(v1.x, v2.x, cv.x, sv.x, v1.x, v2.x);
@@ -78,7 +78,12 @@ __global__ __launch_bounds__(256) void rope_store_kernel(RopeStoreArgs a) {
             st16(base + (a.d >> 1) + c * 8, v2);
         }
         if (h >= a.hq) {
-            const int pg = a.block_table[(int64_t)b * a.bt_stride + (pos >> a.page_shift)];
+            // a position before the table or past its last column belongs to no page of this
+            // sequence: reading that entry would take the next row's page ids (or run off the
+            // buffer) and the store would land in another sequence's page
+            const int pcol = pos >> a.page_shift;
+            if (pos < 0 || pcol >= a.bt_stride) continue;
+            const int pg = a.block_table[(int64_t)b * a.bt_stride + pcol];
             if (pg < 0 || pg >= a.num_pages) continue;  // unallocated: nothing to write to
             const bool is_v = h >= a.hq + a.hkv;
             const int kvh = h - a.hq - (is_v ? a.hkv : 0);
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
     const int qb = a.nqb - 1 - (int)(blockIdx.x / per);
     const int rem = blockIdx.x % per;
     const int kvh = rem % a.hkv, b = rem / a.hkv;
-    const int p0 = a.start[b];
+    const int p0 = max(a.start[b], 0);   // a negative start is a contract breach: treated as 0
     const int i0 = qb * a.qt;
     const int last_key = p0 + min(i0 + a.qt, a.S) - 1;   // last key any row of this block sees
     const int ntiles = last_key / KT + 1;
@@ -181,8 +186,10 @@ __global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
 
     // K/V staging: thread moves vectors t + 256 j of the 64 x VPR tile
     auto tile_page = [&](int t) {
-        const int pg = bt[(t * KT) >> a.page_shift];
-        return (pg >= 0 && pg < a.num_pages) ? pg : 0;   // contract breach: stay inside the cache
+        // column clamped into the table: keys past its last column have no page (a contract breach:
+        // such keys read page-table garbage before; now they read the last column's page)
+        const int pg = bt[min((t * KT) >> a.page_shift, a.bt_stride - 1)];
+        return (pg >= 0 && pg < a.num_pages) ? pg : 0;   // unallocated entry: stay inside the cache
     };
     auto g_load = [&](uint4(&kr)[NV], uint4(&vr)[NV], int t, int pg) {
 #pragma unroll

@@ -321,3 +321,61 @@ def test_requests_that_cannot_be_scheduled_are_refused_at_intake(mv):
         eng.add_request("", max_tokens=4)
     assert not eng.scheduler.waiting_queue
     assert len(eng.generate(["x" * 64], max_tokens=447, temperature=0.0)) == 1   # exactly at both limits
+
+
+def test_outputs_do_not_depend_on_what_recycled_pages_held(mv):
+    """The position numbering leaves one slot per sequence unwritten and attended (index S after a
+    prompt of S tokens).  The engine zeroes it on the first decode step, so the same greedy prompt
+    gives the same tokens on a fresh pool and on a pool whose pages a previous request filled; with
+    the zeroing off (the reference's behaviour) the dirty pool may change them."""
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES["tiny-gqa"]
+    tok = Tok(cfg.vocab_size)
+    prompts = ["the quick brown fox " * 3, "pack my box with five dozen liquor jugs", "xy"]
+
+    def run(dirty):
+        gpu_model = build_synthetic_model(cfg, "cpu", seed=1234, norm_jitter=0.1).to(DEV)
+        eng = InferenceEngine(model=gpu_model, tokenizer=tok, max_batch_size=4, n_blocks=6, max_tokens=512,
+                              graph_batch_sizes=[1, 2, 4], prefill_timeout=0.0)
+        if dirty:   # what recycled pages look like: every slot of the pool holds somebody's keys
+            g = torch.Generator(device=DEV).manual_seed(9)
+            eng.cache_manager._k_store.normal_(0.0, 3.0, generator=g)
+            eng.cache_manager._v_store.normal_(0.0, 3.0, generator=g)
+        out = eng.generate(prompts, max_tokens=8, temperature=0.0)
+        assert eng.cache_manager.stats["free"] == 6
+        return out
+
+    clean, dirty = run(False), run(True)
+    assert clean == dirty
+
+
+def test_first_token_from_the_last_real_position(mv):
+    """`sample_last_real_token=True`: a short prompt batched with a longer one gets its first token
+    from its own last token's logits - the token it gets when it is prefilled alone - instead of
+    from the pad position (the reference's behaviour, which stays the default)."""
+    from micro_vllm_amd.core.engine import InferenceEngine
+    from micro_vllm_amd.core.inference_context import BatchInferenceContext
+    from micro_vllm_amd.models import SHAPES, build_synthetic_model
+
+    cfg = SHAPES["tiny-gqa"]
+    tok = Tok(cfg.vocab_size)
+    short, long_ = "abcdefg", "hello world, this is a longer prompt!!"
+
+    def first_tokens(prompts, flag):
+        gpu_model = build_synthetic_model(cfg, "cpu", seed=1234, norm_jitter=0.1).to(DEV)
+        eng = InferenceEngine(model=gpu_model, tokenizer=tok, max_batch_size=4, n_blocks=8, max_tokens=512,
+                              graph_batch_sizes=[1, 2, 4], prefill_timeout=0.0, sample_last_real_token=flag)
+        for p in prompts:
+            eng.add_request(p, max_tokens=2, temperature=0.0)
+        batch, kind = eng.get_next_batch()
+        assert kind == "prefill" and len(batch) == len(prompts)
+        assert eng.step(BatchInferenceContext(len(batch), kind, batch))
+        return {s.prompt: s._next_token for s in batch}
+
+    alone = first_tokens([short], True)[short]
+    assert first_tokens([short], False)[short] == alone              # no padding: the flag changes nothing
+    together = first_tokens([short, long_], True)
+    assert together[short] == alone
+    assert together[long_] == first_tokens([long_], False)[long_]

@@ -205,3 +205,43 @@ def test_decode_continues_on_the_pages_prefill_wrote(mv):
     want = ref.decode(nxt, [(ref_cache.k_caches, ref_cache.v_caches)], rsl, rbt).float()
     assert (got - want).abs().mean().item() <= 4e-3
     assert torch.equal(got.argmax(-1), want.argmax(-1))
+
+
+def test_tokens_past_the_block_table_width_touch_no_other_sequence(mv):
+    """start + S beyond the last block-table column (a caller error the engine's intake check
+    prevents, reachable through the op-level call): the rows that have a page are stored, the ones
+    past the table are dropped - nothing is read from the next row's page ids, nothing of any other
+    sequence's pages changes, and attention stays finite."""
+    from micro_vllm_amd.core.paged_attention import flash_attn_with_kvcache
+    from micro_vllm_amd.core.prefill_attention import rope_store_prefill
+
+    B, S, Hq, Hkv, D, page, W = 2, 100, 8, 2, 128, 256, 2
+    g = torch.Generator().manual_seed(3)
+    n_pages = 8
+    kc = torch.randn(n_pages, page, Hkv, D, generator=g).to(torch.bfloat16)
+    vc = torch.randn(n_pages, page, Hkv, D, generator=g).to(torch.bfloat16)
+    bt = torch.tensor([[5, 1], [3, 6]], dtype=torch.int32)          # 2 columns: 512 positions per row
+    starts = torch.tensor([450, 0], dtype=torch.int32)              # row 0 runs 38 tokens past its table
+    qkv = torch.randn(B * S, (Hq + 2 * Hkv) * D, generator=g).to(torch.bfloat16)
+    cos, sin = rotary_tables_ref(D, 2048)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    rope_store_prefill(qkv.to(DEV), B, S, Hq, Hkv, D, kcd, vcd, starts.to(DEV), bt.to(DEV), cos.to(DEV), sin.to(DEV))
+    torch.cuda.synchronize()
+    changed = (kcd.cpu() != kc).flatten(2).any(-1) | (vcd.cpu() != vc).flatten(2).any(-1)    # [page, slot]
+    allowed = torch.zeros_like(changed)
+    allowed[1, 450 - 256:] = True           # row 0: positions 450..511 on its second page
+    allowed[3, :100] = True                 # row 1: positions 0..99 on its first page
+    assert not bool((changed & ~allowed).any()), (changed & ~allowed).nonzero().tolist()
+    assert bool(changed[1, 450 - 256:].all()) and bool(changed[3, :100].all())
+    q = torch.randn(B, S, Hq, D, generator=g).to(torch.bfloat16)
+    k = torch.randn(B, S, Hkv, D, generator=g).to(torch.bfloat16)
+    out = flash_attn_with_kvcache(q.to(DEV), kcd, vcd, k=k.to(DEV), v=k.to(DEV), cache_seqlens=starts.to(DEV),
+                                  block_table=bt.to(DEV), causal=True)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(out.float()).all())
+    # row 1 is a well-formed call: it still matches the oracle
+    kc1, vc1 = kcd.cpu().clone(), vcd.cpu().clone()
+    kc0, vc0 = kc1.clone(), vc1.clone()
+    want = flash_attn_with_kvcache_ref(q[1:], kc0, vc0, k[1:], k[1:], None, None, starts[1:], bt[1:], causal=True,
+                                       p_bf16=True)
+    assert_close_bf16(out[1:].cpu(), want, atol=4e-3, rtol=2 ** -6, what="well-formed row")
