@@ -49,6 +49,18 @@ def _cast_impl_rne(self, src, dst_type):
 _interp.InterpreterBuilder.cast_impl = _cast_impl_rne
 
 
+class unpatched_interpreter:
+    """The interpreter as it ships (fp32 -> bf16 by truncation) for the duration of a block: the
+    same kernels are recorded a second time with it, so that the fixtures do not rest on the
+    replaced conversion alone."""
+
+    def __enter__(self):
+        _interp.InterpreterBuilder.cast_impl = _orig_cast_impl
+
+    def __exit__(self, *exc):
+        _interp.InterpreterBuilder.cast_impl = _cast_impl_rne
+
+
 def u16(t):
     return t.contiguous().view(torch.int16).numpy().view(np.uint16)
 
@@ -81,6 +93,15 @@ def gen_norms():
                     f"c{ci}_eps": np.float64(eps), f"c{ci}_rmsnorm_decode": u16(y),
                     f"c{ci}_rmsnorm_prefill": u16(y2), f"c{ci}_addnorm_y": u16(yn),
                     f"c{ci}_addnorm_res": u16(res)})
+        with unpatched_interpreter():   # the literal outputs of the interpreter as it ships
+            ty, tyn, tres = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+            _rmsnorm_gemm_kernel[(rows,)](x, ty, w, x.stride(0), ty.stride(0), n, eps,
+                                          BLOCK_SIZE=min(triton.next_power_of_2(n), 2048))
+            _rmsnorm_residual_fused_for_gemm_kernel[(rows,)](
+                x, r, tyn, tres, w, x.stride(0), r.stride(0), tyn.stride(0), tres.stride(0), n, eps,
+                BLOCK_SIZE=min(triton.next_power_of_2(n), 8192))
+        out.update({f"c{ci}_rmsnorm_decode_unpatched": u16(ty), f"c{ci}_addnorm_y_unpatched": u16(tyn),
+                    f"c{ci}_addnorm_res_unpatched": u16(tres)})
     out["n_cases"] = np.int64(len(cases))
     np.savez_compressed(os.path.join(OUT, "norms.npz"), **out)
 
@@ -99,6 +120,11 @@ def gen_swiglu():
         _swiglu_kernel[(triton.cdiv(n_el, 4096),)](gu.view(-1), o.view(-1), n_el, stride_d=2 * d,
                                                   BLOCK_SIZE=4096)
         out.update({f"c{ci}_gate_up": u16(gu), f"c{ci}_out": u16(o)})
+        with unpatched_interpreter():
+            to = torch.empty(rows, d, dtype=torch.bfloat16)
+            _swiglu_kernel[(triton.cdiv(n_el, 4096),)](gu.view(-1), to.view(-1), n_el, stride_d=2 * d,
+                                                      BLOCK_SIZE=4096)
+        out[f"c{ci}_out_unpatched"] = u16(to)
     out["n_cases"] = np.int64(len(cases))
     np.savez_compressed(os.path.join(OUT, "swiglu.npz"), **out)
 
