@@ -25,6 +25,7 @@ SOURCES = [
     "gemm_prefill.hip",
     "sampler.hip",
     "allreduce.hip",
+    "decode_chain.hip",
 ]
 
 # -ffp-contract=off: rounding is part of the parity contract; FMAs are written explicitly

@@ -22,8 +22,8 @@ import torch
 from .. import parallel_config as pc
 from ..paged_attention import PagedAttention, paged_attn_decode
 from ... import _native as nv
-from ...kernel.linear import (StreamedWeight, add_, embedding, gemm_workspace, wgemm, wgemm_norm,
-                              wgemm_postnorm, wgemm_slabs)
+from ...kernel.linear import (StreamedWeight, add_, chain_phase, decode_chain, embedding, gemm_workspace,
+                              wgemm, wgemm_norm, wgemm_postnorm, wgemm_slabs)
 from ...kernel.rmsnorm_add import rmsnorm_
 from ...kernel.rmsnorm_residual import rmsnorm_residual_gemm
 from ...kernel.swiglu import swiglu_gemm
@@ -85,11 +85,15 @@ class ModelGraphRunner:
                  hidden_dim: int, intermediate_size: int, device: str, max_batch_size: int = 32,
                  dtype: torch.dtype = torch.bfloat16, top_k: int = 1000, fused: bool = True,
                  max_blocks: int = 32, exact_rope: bool = False, release_source_weights: bool = False,
-                 reducer=None, tp_rank: int = None, tp_world: int = None):
+                 reducer=None, tp_rank: int = None, tp_world: int = None, chain: bool = False):
         """num_heads / kv_num_heads / intermediate_size are the PER-RANK values (already divided
         by the tensor-parallel world size), intermediate_size counting gate and up together,
         exactly as the reference's engine passes them (core/engine.py:108-114).
 
+        `chain=True` issues the projections of a small batch (bs <= 4, one rank) as one launch per
+        block with grid barriers between them (`_decode_chained`) instead of separate launches;
+        the results are the same bits either way.  Off by default: measured on MI355X the two are
+        equally fast (both stream weights at about 94 % of what a copy kernel reaches).
         `reducer` (kernel/allreduce.py interface) replaces the process group's reduction, and
         `tp_rank` / `tp_world` the process group's rank and size: a single process can then run
         the step of any one rank of a tensor-parallel group (tests, per-rank benchmarks)."""
@@ -101,6 +105,7 @@ class ModelGraphRunner:
             assert reducer is not None and 0 <= tp_rank < tp_world
             self.rank, self.world_size = tp_rank, tp_world
         self._reducer = reducer
+        self.chain = chain
         self.num_heads = num_heads
         self.kv_num_heads = kv_num_heads
         self.intermediate_size = intermediate_size
@@ -133,6 +138,7 @@ class ModelGraphRunner:
         self.uneven_ratio = None
         self._is_graph_ready = False
         self._num_splits: Dict[int, int] = {}
+        self._chain_ok: Dict[int, bool] = {}
 
     # ------------------------------------------------------------------ init
     def prepare_weights(self):
@@ -215,6 +221,8 @@ class ModelGraphRunner:
             need = max(need, L.mv_wgemm_postnorm_workspace_bytes(max_b, self.hidden_dim, k))
         self._gemm_ws = gemm_workspace(dev, max(need, 16))
         self._attn_ws = None
+        # arrival counter of the chained projections' grid barrier (zero-initialised, never reset)
+        self._chain_ws = torch.zeros((L.mv_decode_chain_workspace_bytes() + 3) // 4, dtype=torch.float32, device=dev)
         # this runner's own meeting place for the parts of the greedy pick (zero-initialised tickets)
         self._argmax_ws = torch.zeros((L.mv_argmax_workspace_bytes() + 3) // 4, dtype=torch.float32, device=dev)
 
@@ -358,6 +366,9 @@ class ModelGraphRunner:
         h = embedding(self.model.transformer.wte.weight, input_ids, self._hidden0[:bs])
         if self.fused and self.world_size > 1 and self._reducer.fits(bs, self.hidden_dim):
             logits = self._decode_tp(h, bs, cache_manager)
+        elif self.fused and bs <= 4 and self.chain and self.world_size == 1 and \
+                (logits := self._decode_chained(h, bs, cache_manager)) is not None:
+            pass
         elif self.fused and bs <= 4:
             pend = None
             for layer_idx in range(self.num_layers):
@@ -432,6 +443,54 @@ class ModelGraphRunner:
                            normed, residual=self._residual[:bs], var_from_rounded=True, workspace=ws)
             h = self._mlp_out[:bs]
         return wgemm(normed, self._lm_head, self._logits[:bs], workspace=ws)
+
+    def _decode_chained(self, h, bs, cache_manager):
+        """bs <= 4 on one GPU: after a block's attention, its O, gate/up and down projections and the
+        NEXT block's QKV projection (the LM head after the last block) run as ONE launch with grid
+        barriers between them (`decode_chain`), so a block is two launches - attention, projections -
+        instead of five.  Same arithmetic, bit for bit, as `_layer_norm_fused`.  Returns None, having
+        launched nothing, when the library does not chain this model's shapes."""
+        tr = self.model.transformer
+        blocks = tr.h
+        hq, hkv, d = self.num_heads, self.kv_num_heads, self.head_size
+        qkv, attn_buf = self._qkv[:bs], self._attn[:bs]
+
+        def phases(li, h_in):
+            block = blocks[li]
+            ph = [chain_phase(attn_buf.reshape(bs, -1), block.attn._o, self._attn_out[:bs]),
+                  chain_phase(self._attn_out[:bs], block.mlp._gu, self._swiglu_out[:bs], ln_weight=block.ln_2.weight,
+                              eps=block.ln_2.eps, add_r=h_in, sum_out=self._residual[:bs], swiglu=True),
+                  chain_phase(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs], residual=self._residual[:bs])]
+            if li + 1 < self.num_layers:
+                nb = blocks[li + 1]
+                ph.append(chain_phase(self._mlp_out[:bs], nb.attn._qkv_w, qkv, ln_weight=nb.ln_1.weight,
+                                      eps=nb.ln_1.eps, bias=nb.attn._qkv_b))
+            else:
+                ph.append(chain_phase(self._mlp_out[:bs], self._lm_head, self._logits[:bs],
+                                      ln_weight=tr.ln_f.weight, eps=tr.ln_f.eps))
+            return ph
+
+        if self._chain_ok.get(bs) is False:
+            return None
+        wgemm_norm(h, blocks[0].ln_1.weight, blocks[0].ln_1.eps, blocks[0].attn._qkv_w, qkv,
+                   bias=blocks[0].attn._qkv_b, workspace=self._gemm_ws)
+        for li in range(self.num_layers):
+            k_cache, v_cache = cache_manager.get(li)
+            paged_attn_decode(
+                qkv[:, :hq * d].unflatten(1, (hq, d)), qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)),
+                qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d)), k_cache, v_cache,
+                cache_manager._cache_seqlens_buffer[:bs], cache_manager._block_table_buffer[:bs],
+                self.attention._cos_pool, self.attention._sin_pool,
+                num_splits=self._splits_for(bs, cache_manager), out=attn_buf, workspace=self._attn_ws)
+            if not decode_chain(phases(li, h), bs, self._chain_ws):
+                # refused before anything ran (shape rule): nothing but the first QKV projection and
+                # one attention launch happened, and the caller redoes the step from the start
+                assert li == 0
+                self._chain_ok[bs] = False
+                return None
+            h = self._mlp_out[:bs]
+        self._chain_ok[bs] = True
+        return self._logits[:bs]
 
     def _decode_tp(self, h, bs, cache_manager):
         """Several ranks, any batch size: each of the two reductions of a block (after the O and

@@ -759,6 +759,18 @@ static int pick_ksplit(int m, int nt, int kt) {
     return best;
 }
 
+// Waves per workgroup of the dot form for a projection of `nunits` units of `kt` k-tiles each (the
+// rule above wgemm_impl's launch explains the numbers).  decode_chain.hip runs projections in the
+// same shape, so that its sums are formed in the same order.
+static int dot_form_waves_for_units(int nunits, int kt) {
+    const int cus = num_cus();
+    const bool one_long_strip_per_cu = nunits <= cus && nunits * 8 >= cus * 7 && kt >= 128;
+    const int forced = g_tune_waves;
+    return forced ? forced : (one_long_strip_per_cu ? 16 : 8);
+}
+int dot_form_ksplit(int m, int nt, int kt) { return g_tune_contig ? 0 : pick_ksplit(m, nt, kt); }
+int dot_form_waves(int m, int nt, int kt) { return dot_form_waves_for_units(nt * pick_ksplit(m, nt, kt), kt); }
+
 template <int M, int GW, int PRO>
 static int launch_dot(const GemmArgs& a, int grid, hipStream_t s) {
     constexpr int U = (M <= 2) ? 4 : 2;  // tiles per stage (register budget: 128 VGPRs at 16 waves per CU)
@@ -916,9 +928,8 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     // per CU even out the tail (QKV 12.8 -> 11.3 us, gate/up 39.1 -> 37.6).
     // Sixteen waves only pay when nearly every CU has a strip and the strip is long: shards with
     // short k (K=1792: 4.8 vs 5.8 us) or few strips (48: 5.4 vs 5.8) are faster with eight.
-    const bool one_long_strip_per_cu = a.nunits <= cus && a.nunits * 8 >= cus * 7 && a.kt >= 128;
-    const int forced_waves = g_tune_waves, forced_bpc = g_tune_bpc;
-    int waves = forced_waves ? forced_waves : (one_long_strip_per_cu ? 16 : 8);
+    const int forced_bpc = g_tune_bpc;
+    int waves = dot_form_waves_for_units(a.nunits, a.kt);
     int bpc = forced_bpc ? forced_bpc : (m <= 4 && waves == 8 ? 2 : 1);
     if (m <= 4) {
         // LDS limits co-residency; never size the grid past what fits
