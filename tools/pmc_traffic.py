@@ -1,7 +1,7 @@
 """HBM traffic per launch of the dominant decode kernel from two rocprofv3 --pmc passes
 (FETCH_SIZE and WRITE_SIZE, each collected in a run of its own):
 
-  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> KEY
+  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> KEY [SOURCE]
 
 FETCH_SIZE and WRITE_SIZE are reported in KiB.  On gfx950 FETCH_SIZE counts 64 bytes per
 128-byte request of a wide streaming read, so it is doubled.  Writes the per-launch average
@@ -27,6 +27,7 @@ def per_launch(path, counter, kernel_substr):
 
 def main():
     fetch_csv, write_csv, key = sys.argv[1:4]
+    source = sys.argv[4] if len(sys.argv) > 4 else None
     kernel = key.split(":")[0]
     f, nf = per_launch(fetch_csv, "FETCH_SIZE", kernel)
     w, nw = per_launch(write_csv, "WRITE_SIZE", kernel)
@@ -39,6 +40,8 @@ def main():
     d[key + ":detail"] = {"launches": nf, "fetch_bytes_per_launch": int(fetch_b),
                           "write_bytes_per_launch": int(write_b),
                           "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE KiB x 1024"}
+    if source:
+        d[key + ":detail"]["source"] = source
     json.dump(d, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps({key: d[key], "detail": d[key + ":detail"]}))
 
