@@ -504,23 +504,34 @@ def main():
         lat.append(e0.elapsed_time(e1))
         pos += 1
     lat.sort()
-    # ---- and, with more than one rank, what the 2 x layers all-reduces of a step cost alone ----
-    allreduce_us = None
+    # ---- and, with more than one rank, what the 2 x layers reductions of a step cost alone: the
+    # runner's own reducer (one-shot all-reduce fused with add + RMSNorm, or torch.distributed + norm
+    # kernels), issued back to back the way the step issues them ----
+    allreduce_us, allreduce_kind = None, None
     if world > 1:
         try:
-            buf = torch.zeros(bs, cfg.hidden_size, dtype=torch.bfloat16, device=dev)
-            for _ in range(4):
-                pc.all_reduce(buf)
+            red = runner._reducer
+            allreduce_kind = type(red).__name__
+            n = cfg.hidden_size
+            part = torch.zeros(bs, n, dtype=torch.bfloat16, device=dev)
+            resid, y, normed = (torch.zeros(bs, n, dtype=torch.bfloat16, device=dev) for _ in range(3))
+            lnw = torch.ones(n, dtype=torch.bfloat16, device=dev)
+
+            def ops(k):
+                for _ in range(k):
+                    red.addnorm(bs, n, partial=part, residual=resid, y=y, ln_weight=lnw, eps=1e-5, normed=normed)
+
+            ops(4)
             sync_all()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(2 * layers):
-                pc.all_reduce(buf)
+            ops(2 * layers)
             e1.record()
             e1.synchronize()
             allreduce_us = e0.elapsed_time(e1) * 1e3 / (2 * layers)
+            sync_all()
         except Exception as e:
-            log(f"[bench] all-reduce timing failed: {e!r}")
+            log(f"[bench] reduction timing failed: {e!r}")
 
     ms_per_step = dt / args.steps * 1e3
     tok_s = bs * args.steps / dt
@@ -570,9 +581,10 @@ def main():
         out["step_ms_median"] = round(lat[len(lat) // 2], 4)
         out["step_ms_p99"] = round(lat[min(len(lat) - 1, int(len(lat) * 0.99))], 4)
     if allreduce_us is not None:
-        # eager launches of the same [bs, hidden] bf16 sum, back to back; the step issues 2 per layer
         out["allreduce"] = {"us_per_op": round(allreduce_us, 2), "ops_per_step": 2 * layers,
-                            "share_of_step": round(allreduce_us * 2 * layers / (ms_per_step * 1e3), 4)}
+                            "share_of_step": round(allreduce_us * 2 * layers / (ms_per_step * 1e3), 4),
+                            "reducer": allreduce_kind,
+                            "what": "[bs, hidden] sum over the ranks + residual add + RMSNorm, eager launches back to back"}
 
     if rank == 0:
         try:
