@@ -823,8 +823,14 @@ static int mfma_strip_group(int mb, int nt) {
     // group - the x traffic out of L2 dominates otherwise (M=32, down projection: 41.7 us with
     // single strips against 25.9 us with groups of four).  One row block: the largest group that
     // still leaves about one workgroup per CU, because sharing only pays once every CU has work.
-    if (mb >= 2) return most;
     const int want = num_cus() * 3 / 4;
+    // ... unless groups of two strips fill the chip without a k-split where groups of four do not:
+    // the split costs a second launch that adds the slabs (Llama-3-8B QKV at M = 32: 16.2 us with
+    // pairs against 18.2 us with groups of four in two k-slices, 14.1 against 16.0 at M = 24; at
+    // M = 48 the two are equal and at M = 64 the x traffic of pairs costs more than the split:
+    // 23.1 against 21.8 us)
+    if (mb == 2) return ((nt + most - 1) / most < want && (nt + 1) / 2 >= want) ? 2 : most;
+    if (mb > 2) return most;
     for (int sg = most; sg > 1; sg >>= 1)
         if ((nt + sg - 1) / sg >= want) return sg;
     return 1;
