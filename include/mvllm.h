@@ -372,6 +372,8 @@ int mv_allreduce_init(int rank, int world, int max_rows, int max_n, void** comm_
 int mv_allreduce_get_handle(void* comm, void* handle_out);
 int mv_allreduce_connect(void* comm, const void* handles);
 int mv_allreduce_status(void* comm, int* status_out);
+/* How long later step calls wait for a peer (overrides MVLLM_ALLREDUCE_TIMEOUT_MS for this communicator). */
+int mv_allreduce_set_timeout_ms(void* comm, double ms);
 int mv_allreduce_destroy(void* comm);
 
 /* out = bf16(sum over ranks of in), [rows, n] bf16; out may alias in. */

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "mv_allreduce_get_handle": (_I, [_P, _P]),
     "mv_allreduce_connect": (_I, [_P, _P]),
     "mv_allreduce_status": (_I, [_P, ctypes.POINTER(c_int)]),
+    "mv_allreduce_set_timeout_ms": (_I, [_P, ctypes.c_double]),
     "mv_allreduce_destroy": (_I, [_P]),
     "mv_allreduce_step": (_I, [_P, _P, _L, _P, _L, _I, _I, _P]),
     "mv_allreduce_addnorm": (_I, [_P, _P, _L, _P, _I, _P, _L, _P, _L, _P, _F, _P, _L, _I, _I, _I, _P]),

@@ -113,6 +113,15 @@ def tensor_parallel_reducer(max_rows: int, max_n: int):
             ok = 1
         except Exception as e:
             log.warning("one-shot all-reduce: rank %d cannot map its peers: %r", get_rank(), e)
+    mapped = [None] * world
+    dist.all_gather_object(mapped, ok, group=group)
+    if all(v == 1 for v in mapped):
+        # everybody mapped everybody: one known sum through the buffers before they are trusted
+        if not comm.self_test():
+            log.warning("one-shot all-reduce: self-test failed on rank %d", get_rank())
+            ok = 0
+    else:
+        ok = 0
     votes = [None] * world
     dist.all_gather_object(votes, ok, group=group)
     if all(v == 1 for v in votes):

@@ -301,6 +301,12 @@ int mv_allreduce_connect(void* comm, const void* handles) {
     return MV_OK;
 }
 
+int mv_allreduce_set_timeout_ms(void* comm, double ms) {
+    if (!comm || !(ms > 0.0)) return MV_ERR_INVALID_ARG;
+    ((mv::ArComm*)comm)->timeout_ticks = (unsigned long long)(ms * 1.0e5);   // 100 MHz
+    return MV_OK;
+}
+
 int mv_allreduce_status(void* comm, int* status_out) {
     if (!comm || !status_out) return MV_ERR_INVALID_ARG;
     hipError_t e = hipMemcpy(status_out, ((mv::ArComm*)comm)->status, sizeof(int), hipMemcpyDeviceToHost);

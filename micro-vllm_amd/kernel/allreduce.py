@@ -68,6 +68,33 @@ class IpcAllReduce:
     def fits(self, rows: int, n: int) -> bool:
         return rows <= self.max_rows and n <= self.max_n and n % 8 == 0
 
+    def set_timeout_ms(self, ms: float):
+        nv.check("mv_allreduce_set_timeout_ms", nv.lib().mv_allreduce_set_timeout_ms(self._comm, float(ms)))
+
+    def self_test(self, timeout_ms: float = 3000.0) -> bool:
+        """One known sum through the mapped buffers, every rank at once: rank r contributes r + 1 in
+        every element, so each rank must read world * (world + 1) / 2 everywhere, twice in a row (both
+        data slots), with no wait timing out.  Run by all ranks right after `connect`, before the
+        communicator is trusted with a decode step: a link that maps but does not deliver ends
+        here, in seconds, instead of in a step that waits out the full timeout 64 times."""
+        import os
+        n = min(self.max_n, 1024)
+        want = float(self.world * (self.world + 1) // 2)
+        self.set_timeout_ms(timeout_ms)
+        ok = True
+        try:
+            for _ in range(2):
+                x = torch.full((1, n), float(self.rank + 1), dtype=torch.bfloat16, device="cuda")
+                self.all_reduce(x)
+                torch.cuda.synchronize()
+                ok = ok and bool((x.float() == want).all())
+            ok = ok and self.status() == 0
+        except Exception:
+            ok = False
+        default = float(os.environ.get("MVLLM_ALLREDUCE_TIMEOUT_MS", "10000") or 10000)
+        self.set_timeout_ms(default if default > 0 else 10000.0)
+        return ok
+
     def status(self) -> int:
         """0 unless a wait for a peer timed out since the communicator was made (synchronises)."""
         st = ctypes.c_int(0)
