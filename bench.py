@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-bs32", action="store_true", help="skip the batch-32 legs of the report")
     ap.add_argument("--chain", action="store_true",
                     help="A/B switch: one launch per block for the projections of a small batch (grid barriers)")
+    ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
+                    help="one process, no peers: build and run rank 0 of a tensor-parallel group of N "
+                         "(the several-ranks launch sequence; its reductions sum one partial)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tail-steps", type=int, default=50,
                     help="steps timed one by one AFTER the timed region, for the median / p99 step")
@@ -67,13 +70,18 @@ def build(args, dev, world):
     cfg = SHAPES[args.model]
     layers = args.layers or cfg.num_hidden_layers
     model = build_synthetic_model(cfg, dev, seed=1234, num_layers=layers)
+    alone = {}
+    if args.as_rank_of:
+        from micro_vllm_amd.kernel.allreduce import IpcAllReduce
+        assert world == args.as_rank_of
+        alone = dict(reducer=IpcAllReduce(0, 1, max(args.bs, 1), cfg.hidden_size), tp_rank=0, tp_world=world)
     total_tokens = args.ctx + args.steps + args.warmup + args.tail_steps + 8
     blocks_per_seq = (total_tokens + 255) // 256 + 1
     runner = ModelGraphRunner(
         model, layers, cfg.num_attention_heads // world, cfg.head_dim,
         cfg.num_key_value_heads // world, cfg.hidden_size, cfg.intermediate_size // world, dev,
         max_batch_size=args.bs, max_blocks=max(32, blocks_per_seq), release_source_weights=True,
-        chain=args.chain)
+        chain=args.chain, **alone)
     mgr = KVCacheManager(args.bs * blocks_per_seq + 2, 256, layers, cfg.num_key_value_heads // world,
                          cfg.head_dim, dtype=torch.bfloat16, device=dev,
                          max_tokens=blocks_per_seq * 256, max_batch_size=args.bs)
@@ -445,6 +453,10 @@ def main():
     from micro_vllm_amd.core.layer.sampler import greedy
 
     pc.setup()
+    peers = world > 1                 # ranks to synchronise with
+    if args.as_rank_of:
+        assert world == 1, "--as-rank-of runs one process"
+        world = args.as_rank_of       # from here on: the group size the model is cut for
     t_build = time.time()
     cfg, layers, runner, mgr, ctxs = build(args, dev, world)
     bs = args.bs
@@ -469,7 +481,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if peers:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -483,11 +495,11 @@ def main():
         ids = step(ids, pos)
         pos += 1
     torch.cuda.synchronize()
-    if world > 1:
+    if peers:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if peers:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -551,7 +563,7 @@ def main():
         "metric": "decode tokens/sec (paged-KV single-token decode, whole job)",
         "value": round(tok_s, 2),
         "unit": "tokens/s",
-        "n_gpus": world,
+        "n_gpus": 1 if args.as_rank_of else world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
@@ -567,7 +579,8 @@ def main():
             "global_batch": bs,
             "seq_len": args.ctx,
             "layers": layers,
-            "parallelism": f"tp{world}",
+            "parallelism": (f"rank 0 of tp{world} alone on one GPU: no peers, every reduction sums one partial"
+                            if args.as_rank_of else f"tp{world}"),
             "graph": bs in runner._graphs,   # False when capture was skipped or fell back to eager
             # the step replayed the graph with the finer attention split (rows of uneven length)
             "uneven_split_graph": bs in runner._graphs_uneven and runner._rows_uneven(mgr, bs),
@@ -617,7 +630,7 @@ def main():
                 log(f"[bench] cpu baseline failed: {e!r}")
                 out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if peers:
         dist.barrier()
         dist.destroy_process_group()
 

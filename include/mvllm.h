@@ -212,6 +212,11 @@ size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k);
 int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
                        const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,
                        int k, int flags, void* workspace, size_t workspace_bytes, mv_stream_t stream);
+/* Which form a call of that shape takes on the current device (for tests and tools; no counterpart
+ * in the reference): 0 = 128 x 256 tiles, two workgroups per CU, weights straight into registers;
+ * 1 = 256 x 256 tiles, one workgroup per CU, both operands through LDS (taken when its tiles fill
+ * at least half the CUs; MVLLM_PREFILL_WIDE=0/1 forces the choice for a process). */
+int mv_gemm_prefill_form(int m, int n, int k);
 
 /* ---------------------------------------------------- paged attention */
 

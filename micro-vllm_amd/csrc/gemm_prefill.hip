@@ -19,6 +19,8 @@
 // by 8 inside each 16-row tile.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace mv {
 
 constexpr int kPM = 128;            // rows of x per workgroup
@@ -49,6 +51,7 @@ struct PGemmArgs {
     int m, n, k;
     int nt, kt;       // 16-row strips, 32-wide k-tiles
     int mblocks, nblocks, nb_per_xcd;
+    int mband;        // wide form: m-blocks walked together against all n-blocks of an XCD
     int flags;
     // k-split: slice ks of a tile covers k-tiles [ks * ktps, (ks + 1) * ktps) and writes its fp32
     // accumulators to partial[ks][m][n]; a second launch adds the slices and applies the epilogue
@@ -79,6 +82,58 @@ static __device__ unsigned long long g_stamp[4 * 512];
 #else
 #define MV_MFMA(c, a_, b_) c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_, b_, c, 0, 0, 0)
 #endif
+
+// One wave's 64 (n) x 128 (m) block of accumulators to memory, with the projection epilogue:
+// acc[i][t][j] = C[n = 16 (nt0+i) + 4q + j][m = m0 + 16 t + r]
+__device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_t (&acc)[kPNT][kPMT], int nt0,
+                                                int m0, int ks, int r, int q) {
+    const bool sw = (a.flags & MV_GEMM_SWIGLU) != 0, of32 = (a.flags & MV_GEMM_OUT_F32) != 0;
+#pragma unroll
+    for (int i = 0; i < kPNT; ++i) {
+        const int nt = nt0 + i;
+        if (nt >= a.nt) continue;  // uniform
+        const int n0 = nt * 16 + q * 4;
+#pragma unroll
+        for (int t = 0; t < kPMT; ++t) {
+            const int m = m0 + t * 16 + r;
+            const f32x4_t c = acc[i][t];
+            if (a.partial) {
+                if (m < a.m)
+                    *reinterpret_cast<f32x4_t*>(&a.partial[((int64_t)ks * a.m + m) * a.n + n0]) = c;
+            } else if (sw) {
+                // rows 0..7 of the tile are up, 8..15 the matching gates: 32 lanes further
+                f32x4_t g;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) g[j] = __shfl_xor(c[j], 32, 64);
+                if (q < 2 && m < a.m) {
+                    uint2 o;
+                    o.x = pack_bf16x2(silu_mul_rounded(g[0], c[0]), silu_mul_rounded(g[1], c[1]));
+                    o.y = pack_bf16x2(silu_mul_rounded(g[2], c[2]), silu_mul_rounded(g[3], c[3]));
+                    *reinterpret_cast<uint2*>(
+                        &reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + nt * 8 + q * 4]) = o;
+                }
+            } else if (m < a.m) {
+                if (of32) {
+                    *reinterpret_cast<f32x4_t*>(&reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n0]) = c;
+                } else {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float tv = round_bf16(c[j]);
+                        if (a.bias) tv = round_bf16(tv + bf16_bits_to_f32(a.bias[n0 + j]));
+                        if (a.residual)
+                            tv = round_bf16(tv + bf16_bits_to_f32(a.residual[(int64_t)m * a.ld_res + n0 + j]));
+                        v[j] = tv;
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(&reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + n0]) = o;
+                }
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char xs[3][kPStage];
@@ -236,53 +291,205 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
     if (s < nstage) stage(wA, wB, wC, s, 0, 1, 2);
     if (s + 1 < nstage) stage(wC, wA, wB, s + 1, 1, 2, 0);
 
-    // acc[i][t][j] = C[n = 16 (nt0+i) + 4q + j][m = m0 + 16 t + r]
-    const bool sw = (a.flags & MV_GEMM_SWIGLU) != 0, of32 = (a.flags & MV_GEMM_OUT_F32) != 0;
+    store_wave_tile(a, acc, nt0, m0, ks, r, q);
+}
+
+
+// ---- the wide form: 256 (n) x 256 (m) outputs per workgroup, both operands through LDS -----------
+// The form above pulls (128 + 256) operand rows through a CU's vector memory path per 128 x 256
+// outputs, and at thousands of tokens that path, not the matrix pipe, sets its pace.  Here eight
+// waves share a 256 x 256 tile - (256 + 256) rows per twice the outputs, a third fewer bytes per
+// multiply-add out of L2 - and nothing goes through registers on the way in: weight tiles (already
+// in fragment order) and x rows are both written to LDS by global_load_lds, the weights four
+// k-tiles ahead of their use, x three 64-wide stages ahead.  Wave w owns n-tiles 4 (w & 3) .. +3
+// against m-tiles 8 (w >> 2) .. +7: the same 64 x 128 block of accumulators as above.
+//
+// LDS (all 160 KiB): x ring 3 x 32 KiB + weight ring 4 x 16 KiB.
+//   weight slot: 16 n-tiles x 1 KiB in fragment order (a tile is copied as it lies in memory);
+//   x slot: 16 m-tiles x 2 KiB, an m-tile = 16 rows x 128 bytes (64 k); the 16-byte chunk c of row
+//   r sits at chunk position c ^ ((r >> 1) & 7) of its row, which makes the fragment reads (lane
+//   (r, q) reads chunk 4 kk + q of row r) free of bank conflicts while every copy instruction
+//   still moves whole 128-byte row segments (8 rows per instruction; the permutation is applied to
+//   the global address of each lane, the LDS side of such a copy is always linear in the lane).
+// Schedule of k-tile kt (stage s = kt / 2): request weight tile kt + 4 into the slot whose
+// fragments were read during kt - 1 and, on odd kt, x stage s + 3 likewise; read the fragments of
+// kt + 1 into the second register set; 32 MFMAs on the first (copies, reads and MFMAs interleaved
+// in eight groups); wait until this wave's pieces of weight tile kt + 2 and of the x stage it
+// belongs to have landed (8 younger requests may be outstanding, on either parity); barrier.
+//
+// Measured on the gate/up projection at 4096 tokens (962 GFLOP): this schedule with no copies
+// and no fragment reads (MFMAs and the barrier alone) 610 us, with the reads 683, with the copies as
+// well 795-810 (1.19-1.21 PFLOP/s; the 128 x 256 form 940).  Each fragment read costs the SIMD about 7
+// cycles of matrix-pipe time and each copy instruction about 27 wherever they stand in the k-tile,
+// and a tile of this size needs 24 + 8 of them per SIMD per 1024 cycles of MFMAs.
+constexpr int kWM = 256, kWN = 256;
+constexpr int kWXSlot = 32768, kWWSlot = 16384;
+constexpr int kWLds = 3 * kWXSlot + 4 * kWWSlot;
+
+__global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    unsigned char* const xring = lds;
+    unsigned char* const wring = lds + 3 * kWXSlot;
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int wn = wid & 3, wm = wid >> 2;
+
+    // blockIdx -> tile.  An XCD (blockIdx mod 8) owns a contiguous range of n-blocks and walks it in
+    // bands of `mband` m-blocks: m fastest inside the band, then n, then the next band - so the 32
+    // workgroups resident on the XCD at one time are mband x 32/mband tiles (8 x 4 at 2048 tokens and
+    // more) rather than one long column, and the operand rows they pull through that XCD's L2
+    // together are as few as 32 tiles allow.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, idx = bid >> 3;
+    const int per_band = a.mband * a.nb_per_xcd;
+    const int band = min(idx / per_band, (a.mblocks - 1) / a.mband);
+    const int rows = min(a.mband, a.mblocks - band * a.mband);
+    const int j = idx - band * per_band;
+    const int nbl = j / rows;
+    const int nb = xcd * a.nb_per_xcd + nbl;
+    const int mb = band * a.mband + j % rows;
+    if (nb >= a.nblocks || nbl >= a.nb_per_xcd) return;
+    const int m0 = mb * kWM;
+    const int ntb = nb * (kWN / 16);
+    const int nstage = a.kt >> 1;
+
+    // ---- copy sources of this wave: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles likewise
+    const uint4* wsrc[2];
 #pragma unroll
-    for (int i = 0; i < kPNT; ++i) {
-        const int nt = nt0 + i;
-        if (nt >= a.nt) continue;  // uniform
-        const int n0 = nt * 16 + q * 4;
+    for (int j = 0; j < 2; ++j) wsrc[j] = a.w + (int64_t)min(ntb + 2 * wid + j, a.nt - 1) * a.kt * 64 + lane;
+    const uint16_t* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = (j & 1) * 8 + (lane >> 3);                 // row of the m-tile
+        const int c = (lane & 7) ^ ((row >> 1) & 7);               // the chunk that lives at position lane & 7
+        xsrc[j] = a.x + (int64_t)min(m0 + (2 * wid + (j >> 1)) * 16 + row, a.m - 1) * a.ldx + c * 8;
+    }
+    const unsigned x_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xring;
+    const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wring;
+    auto copy_w = [&](int kt, int slot) {
+        const int ktc = min(kt, a.kt - 1);   // past the end: a harmless re-fetch keeps the counts fixed
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const uint4* src = wsrc[j] + (int64_t)ktc * 64;
+            const unsigned dst = w_lds + slot * kWWSlot + (2 * wid + j) * 1024;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+        }
+    };
+    auto copy_x = [&](int st, int slot) {
+        const int sc = min(st, nstage - 1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint16_t* src = xsrc[j] + sc * 64;
+            const unsigned dst = x_lds + slot * kWXSlot + (2 * wid + (j >> 1)) * 2048 + (j & 1) * 1024;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+        }
+    };
+    // fragment reads: per-lane byte offsets inside a slot
+    const int xoff0 = (wm * 8) * 2048 + r * 128 + (((0 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 0
+    const int xoff1 = (wm * 8) * 2048 + r * 128 + (((4 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 1
+    const int woff = (wn * 4) * 1024 + lane * 16;
+    auto read_frags = [&](bf16x8_t(&wf)[kPNT], bf16x8_t(&xf)[kPMT], int kt) {
+#if defined(MV_EXP_MFMA_ONLY) || defined(MV_EXP_NO_FRAG_READ)
+        // timing experiment only: operands made up in registers, nothing read
+#pragma unroll
+        for (int i = 0; i < kPNT; ++i) wf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(lane * 77 + kt, i * 0x3f803f80u, kt * 0x01010101u, 0x3c003c00u));
+#pragma unroll
+        for (int t = 0; t < kPMT; ++t) xf[t] = __builtin_bit_cast(bf16x8_t, make_uint4(lane * 31 + t, kt * 0x00810081u, 0x3f003f00u + t, 0x3d803d80u));
+        return;
+#endif
+        const int st = kt >> 1;
+        const unsigned char* wp = wring + (kt & 3) * kWWSlot + woff;
+        const unsigned char* xp = xring + (st % 3) * kWXSlot + ((kt & 1) ? xoff1 : xoff0);
+#pragma unroll
+        for (int i = 0; i < kPNT; ++i)
+            wf[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + i * 1024));
+#pragma unroll
+        for (int t = 0; t < kPMT; ++t)
+            xf[t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp + t * 2048));
+    };
+
+    f32x4_t acc[kPNT][kPMT];
+#pragma unroll
+    for (int i = 0; i < kPNT; ++i)
+#pragma unroll
+        for (int t = 0; t < kPMT; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    copy_x(0, 0);
+    copy_x(1, 1);
+    copy_x(2, 2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) copy_w(j, j);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    bf16x8_t wA[kPNT], xA[kPMT], wB[kPNT], xB[kPMT];
+    read_frags(wA, xA, 0);
+    __syncthreads();   // every wave holds k-tile 0 before its slot is written again
+
+    // One k-tile = eight groups of four MFMAs (one m-tile each); the wave's copy instructions and its
+    // twelve fragment reads for the next k-tile are dealt out between the groups instead of standing
+    // in front of them: a copy instruction holds the wave's issue for 60-180 cycles and a burst of
+    // fragment reads for about as long, and with both waves of a SIMD in step (the barrier keeps
+    // them so) the matrix pipe idles through every such block; between short MFMA groups the
+    // partner's MFMAs fill it.
+    auto copy_piece = [&](int kt, bool odd, int p) {
+        // pieces of this k-tile in issue order: on odd k-tiles the four x pieces first
+        const int nx = odd ? 4 : 0;
+        if (p < nx) {
+            const int st = min((kt >> 1) + 3, nstage - 1), slot = (kt >> 1) % 3;
+            const uint16_t* src = xsrc[p] + st * 64;
+            const unsigned dst = x_lds + slot * kWXSlot + (2 * wid + (p >> 1)) * 2048 + (p & 1) * 1024;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+        } else if (p < nx + 2) {
+            const int j = p - nx, ktc = min(kt + 4, a.kt - 1);
+            const uint4* src = wsrc[j] + (int64_t)ktc * 64;
+            const unsigned dst = w_lds + (kt & 3) * kWWSlot + (2 * wid + j) * 1024;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+        }
+    };
+    auto ktile = [&](bf16x8_t(&wc)[kPNT], bf16x8_t(&xc)[kPMT], bf16x8_t(&wnx)[kPNT], bf16x8_t(&xnx)[kPMT], int kt,
+                     bool odd) {
+        const int ktn = min(kt + 1, a.kt - 1);
+        const unsigned char* wp = wring + (ktn & 3) * kWWSlot + woff;
+        const unsigned char* xp = xring + ((ktn >> 1) % 3) * kWXSlot + ((ktn & 1) ? xoff1 : xoff0);
 #pragma unroll
         for (int t = 0; t < kPMT; ++t) {
-            const int m = m0 + t * 16 + r;
-            const f32x4_t c = acc[i][t];
-            if (a.partial) {
-                if (m < a.m)
-                    *reinterpret_cast<f32x4_t*>(&a.partial[((int64_t)ks * a.m + m) * a.n + n0]) = c;
-            } else if (sw) {
-                // rows 0..7 of the tile are up, 8..15 the matching gates: 32 lanes further
-                f32x4_t g;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = __shfl_xor(c[j], 32, 64);
-                if (q < 2 && m < a.m) {
-                    uint2 o;
-                    o.x = pack_bf16x2(silu_mul_rounded(g[0], c[0]), silu_mul_rounded(g[1], c[1]));
-                    o.y = pack_bf16x2(silu_mul_rounded(g[2], c[2]), silu_mul_rounded(g[3], c[3]));
-                    *reinterpret_cast<uint2*>(
-                        &reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + nt * 8 + q * 4]) = o;
-                }
-            } else if (m < a.m) {
-                if (of32) {
-                    *reinterpret_cast<f32x4_t*>(&reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n0]) = c;
-                } else {
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float tv = round_bf16(c[j]);
-                        if (a.bias) tv = round_bf16(tv + bf16_bits_to_f32(a.bias[n0 + j]));
-                        if (a.residual)
-                            tv = round_bf16(tv + bf16_bits_to_f32(a.residual[(int64_t)m * a.ld_res + n0 + j]));
-                        v[j] = tv;
-                    }
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(&reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + n0]) = o;
-                }
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef MV_EXP_NO_COPY
+            if (t < 6) copy_piece(kt, odd, t);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#ifndef MV_EXP_NO_FRAG_READ
+            if (t < 2) {
+                wnx[2 * t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + (2 * t) * 1024));
+                wnx[2 * t + 1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + (2 * t + 1) * 1024));
+            } else if (t < 6) {
+                xnx[2 * t - 4] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp + (2 * t - 4) * 2048));
+                xnx[2 * t - 3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp + (2 * t - 3) * 2048));
             }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < kPNT; ++i)
+                MV_MFMA(acc[i][t], wc[i], xc[t]);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // this wave's pieces of k-tile kt + 2 have landed (8 younger copies may be outstanding), and
+        // its fragment reads of kt + 1 are complete before that slot can be written again
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#ifndef MV_EXP_NO_BARRIER
+        __syncthreads();
+#endif
+    };
+    for (int kt = 0; kt < a.kt; kt += 2) {   // a.kt is even (k is a multiple of 64)
+        ktile(wA, xA, wB, xB, kt, false);
+        ktile(wB, xB, wA, xA, kt + 1, true);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after this workgroup is gone
+
+    if (ntb + wn * 4 >= a.nt) return;
+    store_wave_tile(a, acc, ntb + wn * 4, m0 + wm * 128, 0, r, q);
 }
 
 }  // namespace mv
@@ -319,6 +526,19 @@ static int prefill_ksplit(int m, int n, int kt) {
     }
     return best;
 }
+
+// The wide form (256 x 256 tiles, one workgroup per CU) when its tiles fill the chip; MVLLM_PREFILL_WIDE
+// = 0 / 1 forces the choice (read once).
+static bool prefill_wide(int m, int n, int kt) {
+    static const int forced = [] {
+        const char* e = getenv("MVLLM_PREFILL_WIDE");
+        return e && *e ? atoi(e) : -1;
+    }();
+    if (kt < 8) return false;
+    if (forced >= 0) return forced != 0;
+    const long tiles = (long)((m + kWM - 1) / kWM) * ((n + kWN - 1) / kWN);
+    return 2 * tiles >= num_cus();
+}
 }  // namespace mv
 
 extern "C" size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k) {
@@ -326,6 +546,12 @@ extern "C" size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
     const int ks = prefill_ksplit(m, n, k / 32);
     return ks > 1 ? (size_t)ks * m * n * sizeof(float) : 0;
+}
+
+extern "C" int mv_gemm_prefill_form(int m, int n, int k) {
+    using namespace mv;
+    if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
+    return prefill_ksplit(m, n, k / 32) == 1 && prefill_wide(m, n, k / 32) ? 1 : 0;
 }
 
 extern "C" int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
@@ -369,6 +595,7 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
     a.mblocks = (m + kPM - 1) / kPM;
     a.nblocks = (n + kPN - 1) / kPN;
     a.nb_per_xcd = (a.nblocks + 7) / 8;
+    a.mband = 1;
     a.flags = flags;
     a.ksplit = prefill_ksplit(m, n, a.kt);
     a.partial = nullptr;
@@ -380,6 +607,23 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
             a.ksplit = 1;  // no room for the slices: whole k per tile (slower, same result class)
     }
     a.ktps = a.kt / a.ksplit;
+    if (a.ksplit == 1 && prefill_wide(m, n, a.kt)) {
+        static LdsOptIn lds_done;
+        int rc = ensure_dynamic_lds((const void*)gemm_prefill_wide_kernel, kWLds, lds_done);
+        if (rc != MV_OK) return rc;
+        a.mblocks = (m + kWM - 1) / kWM;
+        a.nblocks = (n + kWN - 1) / kWN;
+        a.nb_per_xcd = (a.nblocks + 7) / 8;
+        a.mband = a.mblocks < 8 ? a.mblocks : 8;
+        if (const char* e = getenv("MVLLM_PREFILL_MBAND")) {   // experiments: 0 = one band (the whole column)
+            const int v = atoi(e);
+            a.mband = v <= 0 || v > a.mblocks ? a.mblocks : v;
+        }
+        const long wgrid = 8L * a.nb_per_xcd * a.mblocks;
+        if (wgrid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(gemm_prefill_wide_kernel, dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
+        return check_launch();
+    }
     const long grid = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
     if (grid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(gemm_prefill_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -70,6 +70,53 @@ def test_gemm_prefill_epilogues(mv):
     assert float((ulp_diff(act, want) == 0).float().mean()) > 0.98
 
 
+@pytest.mark.parametrize("m,n,k,mode", [(1000, 8208, 256, "plain"), (2300, 4096, 512, "residual"),
+                                        (1025, 8192, 320, "bias"), (2048, 4096, 1024, "f32"),
+                                        (700, 22016, 256, "swiglu"), (4096, 2048, 4096, "plain")])
+def test_gemm_prefill_wide_form(mv, m, n, k, mode):
+    """Shapes whose 256 x 256 tiles fill at least half the CUs take the wide form (both operands
+    through LDS, eight waves on a tile): ragged last m- and n-blocks, every epilogue, k from the
+    shortest the form accepts to the model's."""
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    assert nv.lib().mv_gemm_prefill_form(m, n, k) == 1, "this shape is meant to take the wide form"
+    x, w, g = _mk(m, n, k, seed=m + n + k, scale=0.03)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16) if mode == "bias" else None
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16) if mode == "residual" else None
+    swiglu = mode == "swiglu"
+    sw = (StreamedWeight.from_up_gate(w[:n // 2].to(DEV), w[n // 2:].to(DEV)) if swiglu
+          else StreamedWeight.from_linear(w.to(DEV)))
+    ncols = sw.out_features
+    dt = torch.float32 if mode == "f32" else torch.bfloat16
+    xb = torch.zeros(m, k + 64, dtype=torch.bfloat16, device=DEV)       # strided rows in
+    xb[:, :k] = x.to(DEV)
+    yb = torch.full((m, ncols + 32), 7.0, dtype=dt, device=DEV)         # and out
+    gemm_prefill(xb[:, :k], sw, yb[:, :ncols], bias=None if bias is None else bias.to(DEV),
+                 residual=None if res is None else res.to(DEV), swiglu=swiglu)
+    assert torch.all(yb[:, ncols:] == 7.0), "wrote past the row"
+    got = yb[:, :ncols].cpu()
+    want32 = x.float() @ w.float().t()
+    scale = max(1.0, want32.abs().max().item())
+    if mode == "f32":
+        assert (got - want32).abs().max().item() <= 1e-4 * scale
+        return
+    if swiglu:
+        want = swiglu_ref(linear_ref(x, w))
+        assert_close_bf16(got, want, atol=1e-3, rtol=2 ** -6, what="wide form, fused swiglu")
+    else:
+        t0 = linear_ref(x, w).float()
+        t1 = linear_ref(x, w, bias).float()
+        want = t1 if res is None else (t1 + res.float()).to(torch.bfloat16).float()
+        mag = torch.maximum(torch.maximum(t0.abs(), t1.abs()), want.abs())
+        # as for the k-sliced product below: each rounding point may flip by one unit at its own
+        # magnitude between two fp32 summation orders, so two units of the largest intermediate
+        err = (got.float() - want).abs()
+        assert bool((err <= 1e-3 + 2 ** -6 * mag).all()), f"{mode}: max err {err.max().item():.3e}"
+        want = want.to(torch.bfloat16)
+    assert float((ulp_diff(got, want) == 0).float().mean()) > 0.98
+
+
 def test_gemm_prefill_agrees_with_single_token_kernel(mv):
     """Same weights, same rows: the two kernels differ only in fp32 summation order."""
     from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill, wgemm
