@@ -355,36 +355,43 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     const int ntb = nb * (kWN / 16);
     const int nstage = a.kt >> 1;
 
-    // ---- copy sources of this wave: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles likewise
-    const uint4* wsrc[2];
+    // ---- copy sources of this wave: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles likewise.
+    // Every copy is addressed as a wave-uniform 64-bit base (scalar registers, advanced by scalar
+    // adds per k-tile) plus a 32-bit per-lane offset that never changes: no vector arithmetic and
+    // half the address registers per copy instruction.
+    const unsigned char* wbase[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) wsrc[j] = a.w + (int64_t)min(ntb + 2 * wid + j, a.nt - 1) * a.kt * 64 + lane;
-    const uint16_t* xsrc[4];
+    for (int j = 0; j < 2; ++j)
+        wbase[j] = reinterpret_cast<const unsigned char*>(a.w + (int64_t)min(ntb + 2 * wid + j, a.nt - 1) * a.kt * 64);
+    const unsigned wlane = lane * 16;
+    const unsigned char* xbase[2];
+    unsigned xlane[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int row = (j & 1) * 8 + (lane >> 3);                 // row of the m-tile
-        const int c = (lane & 7) ^ ((row >> 1) & 7);               // the chunk that lives at position lane & 7
-        xsrc[j] = a.x + (int64_t)min(m0 + (2 * wid + (j >> 1)) * 16 + row, a.m - 1) * a.ldx + c * 8;
+        const int first = min(m0 + (2 * wid + (j >> 1)) * 16, a.m - 1);   // first row of the m-tile (clamped)
+        const int row = (j & 1) * 8 + (lane >> 3);                          // row of the m-tile
+        const int c = (lane & 7) ^ ((row >> 1) & 7);                        // the chunk that lives at position lane & 7
+        const int grow = min(m0 + (2 * wid + (j >> 1)) * 16 + row, a.m - 1);
+        if ((j & 1) == 0) xbase[j >> 1] = reinterpret_cast<const unsigned char*>(a.x + (int64_t)first * a.ldx);
+        xlane[j] = (unsigned)(((int64_t)(grow - first) * a.ldx + c * 8) * 2);
     }
     const unsigned x_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xring;
     const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wring;
+    auto copy = [&](const unsigned char* base, unsigned lane_off, unsigned dst) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     : : "v"(lane_off), "s"(base), "s"(dst) : "memory");
+    };
     auto copy_w = [&](int kt, int slot) {
         const int ktc = min(kt, a.kt - 1);   // past the end: a harmless re-fetch keeps the counts fixed
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const uint4* src = wsrc[j] + (int64_t)ktc * 64;
-            const unsigned dst = w_lds + slot * kWWSlot + (2 * wid + j) * 1024;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
-        }
+        for (int j = 0; j < 2; ++j)
+            copy(wbase[j] + (int64_t)ktc * 1024, wlane, w_lds + slot * kWWSlot + (2 * wid + j) * 1024);
     };
     auto copy_x = [&](int st, int slot) {
         const int sc = min(st, nstage - 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint16_t* src = xsrc[j] + sc * 64;
-            const unsigned dst = x_lds + slot * kWXSlot + (2 * wid + (j >> 1)) * 2048 + (j & 1) * 1024;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
-        }
+        for (int j = 0; j < 4; ++j)
+            copy(xbase[j >> 1] + sc * 128, xlane[j], x_lds + slot * kWXSlot + (2 * wid + (j >> 1)) * 2048 + (j & 1) * 1024);
     };
     // fragment reads: per-lane byte offsets inside a slot
     const int xoff0 = (wm * 8) * 2048 + r * 128 + (((0 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 0
@@ -438,14 +445,10 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
         const int nx = odd ? 4 : 0;
         if (p < nx) {
             const int st = min((kt >> 1) + 3, nstage - 1), slot = (kt >> 1) % 3;
-            const uint16_t* src = xsrc[p] + st * 64;
-            const unsigned dst = x_lds + slot * kWXSlot + (2 * wid + (p >> 1)) * 2048 + (p & 1) * 1024;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+            copy(xbase[p >> 1] + st * 128, xlane[p], x_lds + slot * kWXSlot + (2 * wid + (p >> 1)) * 2048 + (p & 1) * 1024);
         } else if (p < nx + 2) {
             const int j = p - nx, ktc = min(kt + 4, a.kt - 1);
-            const uint4* src = wsrc[j] + (int64_t)ktc * 64;
-            const unsigned dst = w_lds + (kt & 3) * kWWSlot + (2 * wid + j) * 1024;
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+            copy(wbase[j] + (int64_t)ktc * 1024, wlane, w_lds + (kt & 3) * kWWSlot + (2 * wid + j) * 1024);
         }
     };
     auto ktile = [&](bf16x8_t(&wc)[kPNT], bf16x8_t(&xc)[kPMT], bf16x8_t(&wnx)[kPNT], bf16x8_t(&xnx)[kPMT], int kt,
