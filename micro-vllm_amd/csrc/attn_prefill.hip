@@ -184,6 +184,12 @@ __global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
             qf[mt][ks] = __builtin_bit_cast(bf16x8_t, ld16(qp + ks * 32));
     }
 
+    // the smallest last-key over the wave's 32 rows (its first query position; rows past S repeat S - 1)
+    int wave_min_limit = min(limit[0], limit[1]);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) wave_min_limit = min(wave_min_limit, __shfl_xor(wave_min_limit, o, 64));
+    wave_min_limit = __builtin_amdgcn_readfirstlane(wave_min_limit);
+
     // K/V staging: thread moves vectors t + 256 j of the 64 x VPR tile
     auto tile_page = [&](int t) {
         // column clamped into the table: keys past its last column have no page (a contract breach:
@@ -230,68 +236,109 @@ __global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
+#ifdef MV_EXP_NO_KVLOAD
+        const bool more = false;   // timing experiment only (wrong results): every tile re-uses the first two
+#else
         const bool more = t + 1 < ntiles;
+#endif
         if (more) {
             g_load(kr, vr, t + 1, pg_next);
             if (t + 2 < ntiles) pg_next = tile_page(t + 2);
         }
+        // The 64 keys of the tile in one pass: 32 MFMAs for S^T, one softmax update over 16 scores
+        // per lane and row (one cross-lane maximum, one rescale check), 32 MFMAs for O^T.  (In 32-key
+        // steps the serial parts of the update - lane exchange, exponentials, the running sums -
+        // came round twice as often between MFMA bursts half as long.)
+        const int kb = t * KT;
+        f32x4_t sacc[2][4];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {   // 32-key steps
-            const int kb = t * KT + h * 32;
-            if (kb > last_key) break;   // uniform
-            f32x4_t sacc[2][2];
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int x = 0; x < 4; ++x) sacc[mt][x] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int x = 0; x < 2; ++x) sacc[mt][x] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int x = 0; x < 4; ++x) {
 #pragma unroll
-            for (int x = 0; x < 2; ++x) {
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t kf = __builtin_bit_cast(
+                    bf16x8_t, *reinterpret_cast<const uint4*>(&kL[buf][(x * 16 + r) * KROW + ks * 64 + q * 16]));
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8_t kf = __builtin_bit_cast(
-                        bf16x8_t, *reinterpret_cast<const uint4*>(
-                                      &kL[buf][(h * 32 + x * 16 + r) * KROW + ks * 64 + q * 16]));
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        sacc[mt][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mt][ks], sacc[mt][x], 0, 0, 0);
-                }
+                for (int mt = 0; mt < 2; ++mt)
+                    sacc[mt][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[mt][ks], sacc[mt][x], 0, 0, 0);
             }
-            bf16x8_t pf[2];
+        }
+        bf16x8_t pf[2][2];
+        // tiles wholly at or below every row's last key (all but the one or two on the diagonal)
+        // need no mask; keys past the last valid one were clamped on load and are masked here
+        const bool all_valid = kb + KT - 1 <= wave_min_limit;   // uniform
+#ifdef MV_EXP_NO_SOFTMAX
+        // timing experiment only (wrong results): the scores go to the second product as they are
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                float s[8];
-                float mloc = kPfNegBig;
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int x = 0; x < 2; ++x)
+            for (int h = 0; h < 2; ++h) {
+                uint4 pk;
+                pk.x = pack_bf16x2(sacc[mt][2 * h][0], sacc[mt][2 * h][1]);
+                pk.y = pack_bf16x2(sacc[mt][2 * h][2], sacc[mt][2 * h][3]);
+                pk.z = pack_bf16x2(sacc[mt][2 * h + 1][0], sacc[mt][2 * h + 1][1]);
+                pk.w = pack_bf16x2(sacc[mt][2 * h + 1][2], sacc[mt][2 * h + 1][3]);
+                pf[mt][h] = __builtin_bit_cast(bf16x8_t, pk);
+            }
+        if (false)
+#endif
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            // raw scores; the scale (positive) is applied to the maximum and inside the exponent
+            float s[16];
+            if (all_valid) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) s[x * 4 + j] = sacc[mt][x][j];
+            } else {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int key = kb + x * 16 + q * 4 + j;
-                        const float v = (key <= limit[mt]) ? sacc[mt][x][j] * a.scale_log2 : kPfNegBig;
-                        s[x * 4 + j] = v;
-                        mloc = fmaxf(mloc, v);
+                        s[x * 4 + j] = key <= limit[mt] ? sacc[mt][x][j] : kPfNegBig;
                     }
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-                const float mnew = fmaxf(mrun[mt], mloc);
-                const float alpha = exp2f(mrun[mt] - mnew);
-                mrun[mt] = mnew;
-                float psum = 0.f;
-                float p[8];
+            }
+            float m4[4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    p[e] = exp2f(s[e] - mnew);
-                    psum += p[e];
-                }
-                lrun[mt] = lrun[mt] * alpha + psum;
+            for (int x = 0; x < 4; ++x) m4[x] = fmaxf(fmaxf(s[4 * x], s[4 * x + 1]), fmaxf(s[4 * x + 2], s[4 * x + 3]));
+            float mloc = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])) * a.scale_log2;
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            // the running maximum moves in few tiles once the first are in: the rescale of the 32
+            // output accumulators is skipped while it stands for every row of the wave (a factor
+            // of exactly 1 otherwise: same result)
+            if (__builtin_amdgcn_ballot_w64(mloc > mrun[mt]) != 0) {
+                const float mnew = fmaxf(mrun[mt], mloc);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[mt] - mnew);
+                mrun[mt] = mnew;
+                lrun[mt] *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) oacc[mt][dt] *= alpha;
-                uint4 pk;
-                pk.x = pack_bf16x2(p[0], p[1]);
-                pk.y = pack_bf16x2(p[2], p[3]);
-                pk.z = pack_bf16x2(p[4], p[5]);
-                pk.w = pack_bf16x2(p[6], p[7]);
-                pf[mt] = __builtin_bit_cast(bf16x8_t, pk);
             }
+            const float mnew = mrun[mt];
+            float p[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) p[e] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[e], a.scale_log2, -mnew));
+            // four partial sums: no 16-long chain of dependent adds
+            lrun[mt] += ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])) +
+                        (((p[8] + p[9]) + (p[10] + p[11])) + ((p[12] + p[13]) + (p[14] + p[15])));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 pk;
+                pk.x = pack_bf16x2(p[8 * h + 0], p[8 * h + 1]);
+                pk.y = pack_bf16x2(p[8 * h + 2], p[8 * h + 3]);
+                pk.z = pack_bf16x2(p[8 * h + 4], p[8 * h + 5]);
+                pk.w = pack_bf16x2(p[8 * h + 6], p[8 * h + 7]);
+                pf[mt][h] = __builtin_bit_cast(bf16x8_t, pk);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const unsigned char* vb = &vL[buf][h * 32 * VROW + dt * 32 + tr_off];
@@ -304,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
                 const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, both);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    oacc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mt], oacc[mt][dt], 0, 0, 0);
+                    oacc[mt][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[mt][h], oacc[mt][dt], 0, 0, 0);
             }
         }
         if (more) l_store(kr, vr, buf ^ 1);

@@ -26,8 +26,11 @@ __device__ __forceinline__ uint32_t f32_to_bf16_bits(float f) {
     __bf16 b = (__bf16)f;
     return (uint32_t)__builtin_bit_cast(unsigned short, b);
 }
+// both halves in one v_cvt_pk_bf16_f32 (the scalar cast above costs a convert, a shift and an or per pair)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return f32_to_bf16_bits(lo) | (f32_to_bf16_bits(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 // value after a bf16 round trip
 __device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
