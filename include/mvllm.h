@@ -191,7 +191,7 @@ int mv_decode_chain_status(const void* workspace, int* status_out);
  * key 0 = workgroups per CU the grid is sized for (1..8; 0 = planner, the default);
  * key 1 = forced number of k-slices per strip (0 = pick automatically);
  * key 2 = waves per workgroup of the M <= 4 kernel (8 or 16; 0 = planner);
- * key 3 = strips a workgroup of the M > 4 kernel multiplies together (1, 2, 4; 0 = planner);
+ * key 3 = strips a workgroup of the M > 4 kernel multiplies together (1, 2, 4, 7; 0 = planner);
  * key 4 = tiles of a wave of the M <= 4 kernel consecutive (1) or interleaved (0, the default). */
 int mv_wgemm_tune(int key, int value);
 

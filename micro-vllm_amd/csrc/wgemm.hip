@@ -727,12 +727,26 @@ int launch_wgemm_finalize(float* partial, int ksplit, int m, int n, int flags, c
 // ------------------------------------------------------------ host planning
 // k-slices per strip: balance whole units over the CUs.  Cost in tiles per CU,
 // with a split paying roughly one extra kernel boundary.
-static int mfma_strip_group(int mb, int nt);
+static int mfma_strip_group(int m, int nt, int kt);
+
+// k-slices for `units` whole-k work items: split while fewer than half the CUs would have one and
+// every wave keeps at least 4 tiles
+static int ksplit_for_units(int units, int kt) {
+    const int cus = num_cus();
+    int best = 1;
+    for (int ks = 2; ks <= kMaxKsplit; ks *= 2) {
+        if (kt % ks) break;
+        if (kt / ks < 4 * kGW) break;             // keep >= 4 tiles per wave
+        if ((long)units * best * 2 > cus) break;  // already at least half the CUs busy
+        best = ks;
+    }
+    return best;
+}
 
 // `nt` = work items along N: strips for the dot form, strip groups for the MFMA form.
 static int pick_ksplit(int m, int nt, int kt) {
     if (m > 4) {
-        const int sg = mfma_strip_group((m + 15) / 16, nt);
+        const int sg = mfma_strip_group(m, nt, kt);
         nt = (nt + sg - 1) / sg;
     }
     if (const int forced = g_tune_ksplit; forced > 0) {
@@ -744,19 +758,11 @@ static int pick_ksplit(int m, int nt, int kt) {
     // four decode projections (QKV 11.8 vs 14.8 us, O 8.0 vs 11.4, gate/up 38.8 vs 48.5, down
     // 20.8 vs 23.7): the second launch that adds the slabs costs more than the imbalance of
     // 1.5 strips per CU.  Splitting only pays when there are far fewer strips than CUs.
-    const int cus = num_cus();
     // ... and for the dot form not even then: shards of tensor-parallel runs (tools/sweep_small_gemv.py,
     // M=1) run 5.4 us unsplit against 6.5-8.7 us split at 48 strips (N=768, K=4096), 5.8 against
     // 7.2-10.0 at 96 strips.
     if (m <= 4 && nt >= 32) return 1;
-    int best = 1;
-    for (int ks = 2; ks <= kMaxKsplit; ks *= 2) {
-        if (kt % ks) break;
-        if (kt / ks < 4 * kGW) break;          // keep >= 4 tiles per wave
-        if ((long)nt * best * 2 > cus) break;  // already at least half the CUs busy
-        best = ks;
-    }
-    return best;
+    return ksplit_for_units(nt, kt);
 }
 
 // Waves per workgroup of the dot form for a projection of `nunits` units of `kt` k-tiles each (the
@@ -816,9 +822,15 @@ static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
 
 // strips per workgroup of the MFMA form: the cross-wave reduction buffer is 8 KiB per
 // (strip, row block) pair, 128 KiB for four strips of four row blocks
-static int mfma_strip_group(int mb, int nt) {
+static int mfma_strip_group(int m, int nt, int kt) {
+    const int mb = (m + 15) / 16;
     const int most = 4;
-    if (const int forced = g_tune_sg; forced == 1 || forced == 2 || forced == 4) return forced;
+    if (const int forced = g_tune_sg; forced == 1 || forced == 2 || forced == 4 || (forced == 7 && mb <= 2))
+        return forced;
+    // Seven strips per workgroup where that deals the strips out to the CUs exactly (Llama-3-8B
+    // gate/up: 1792 strips = 7 x 256): in groups of four 448 units fall on 256 CUs as two rounds, the
+    // second three quarters full, and every workgroup re-reads x for four strips instead of seven.
+    if (mb <= 2 && nt % 7 == 0 && (nt / 7) % num_cus() == 0) return 7;
     // From sweeps (tools/sweep_mfma_gemv.py).  Two or more row blocks of x: always the widest
     // group - the x traffic out of L2 dominates otherwise (M=32, down projection: 41.7 us with
     // single strips against 25.9 us with groups of four).  One row block: the largest group that
@@ -831,9 +843,29 @@ static int mfma_strip_group(int mb, int nt) {
     // 23.1 against 21.8 us)
     if (mb == 2) return ((nt + most - 1) / most < want && (nt + 1) / 2 >= want) ? 2 : most;
     if (mb > 2) return most;
-    for (int sg = most; sg > 1; sg >>= 1)
-        if ((nt + sg - 1) / sg >= want) return sg;
-    return 1;
+    // One row block (5-16 rows).  A small model of the three costs, fitted to the Llama-3-8B
+    // projections at 8 and 16 rows (tools/bench_mfma_gemv.py): weights stream at 6.45 MB/us over
+    // the CUs that have a unit, every unit re-reads its k-slice of x out of L2 at about 12.9 MB/us,
+    // and a k-split pays a slab-reduction launch of 4.7 us.  (Down projection, 14336 wide: single
+    // strips win at 8 rows, 21.6 against 22.8 us, and lose at 16, 27.3 against 22.9, because x is
+    // then as many bytes as the weights; the 4096-wide O projection keeps single strips at both,
+    // 9.1 against 11.2 us, its split costing more than its x.)
+    const int cus = num_cus();
+    int best = 1;
+    double best_us = 1e30;
+    for (int sg = most; sg >= 1; sg >>= 1) {
+        const int groups = (nt + sg - 1) / sg;
+        const int ks = ksplit_for_units(groups, kt);
+        const long units = (long)groups * ks;
+        const double fill = (double)units / (double)(((units + cus - 1) / cus) * cus);
+        const double w_mb = (double)nt * kt * 1024e-6, x_mb = (double)units * m * (kt / ks) * 64e-6;
+        const double us = w_mb / (6.45 * fill) + x_mb / 12.9 + (ks > 1 ? 4.7 : 0.0);
+        if (us < best_us) {
+            best_us = us;
+            best = sg;
+        }
+    }
+    return best;
 }
 
 static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_add_r,
@@ -923,7 +955,7 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     }
     a.ktps = a.kt / a.ksplit;
     a.contig = g_tune_contig;
-    const int sg = m > 4 ? mfma_strip_group((m + 15) / 16, a.nt) : 1;
+    const int sg = m > 4 ? mfma_strip_group(m, a.nt, a.kt) : 1;
     a.nunits = ((a.nt + sg - 1) / sg) * a.ksplit;
     a.flags = flags;
 
@@ -956,8 +988,8 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
         case 4: rc = launch_dot_waves<4>(a, waves, grid, s); break;
         default: {
             const int mb = (m + 15) / 16;
-            if (mb == 1) rc = sg == 4 ? launch_mfma<1, 4>(a, grid, s) : sg == 2 ? launch_mfma<1, 2>(a, grid, s) : launch_mfma<1, 1>(a, grid, s);
-            else if (mb == 2) rc = sg == 4 ? launch_mfma<2, 4>(a, grid, s) : sg == 2 ? launch_mfma<2, 2>(a, grid, s) : launch_mfma<2, 1>(a, grid, s);
+            if (mb == 1) rc = sg == 7 ? launch_mfma<1, 7>(a, grid, s) : sg == 4 ? launch_mfma<1, 4>(a, grid, s) : sg == 2 ? launch_mfma<1, 2>(a, grid, s) : launch_mfma<1, 1>(a, grid, s);
+            else if (mb == 2) rc = sg == 7 ? launch_mfma<2, 7>(a, grid, s) : sg == 4 ? launch_mfma<2, 4>(a, grid, s) : sg == 2 ? launch_mfma<2, 2>(a, grid, s) : launch_mfma<2, 1>(a, grid, s);
             else if (mb == 3) rc = sg == 4 ? launch_mfma<3, 4>(a, grid, s) : sg == 2 ? launch_mfma<3, 2>(a, grid, s) : launch_mfma<3, 1>(a, grid, s);
             else rc = sg == 4 ? launch_mfma<4, 4>(a, grid, s) : sg == 2 ? launch_mfma<4, 2>(a, grid, s) : launch_mfma<4, 1>(a, grid, s);
         }
@@ -982,13 +1014,13 @@ extern "C" {
 
 // Tuning hook for experiments: key 0 = workgroups per CU, key 1 = forced ksplit,
 // key 2 = waves per workgroup of the dot form (8 or 16), key 3 = strips per workgroup of the
-// MFMA form (1, 2, 4); 0 = let the planner choose.
+// MFMA form (1, 2, 4, 7); 0 = let the planner choose.
 int mv_wgemm_tune(int key, int value) {
     if (key == 2 && (value == 0 || value == 8 || value == 16)) {
         mv::g_tune_waves = value;
         return MV_OK;
     }
-    if (key == 3 && (value == 0 || value == 1 || value == 2 || value == 4)) {
+    if (key == 3 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7)) {
         mv::g_tune_sg = value;
         return MV_OK;
     }
