@@ -29,6 +29,17 @@ from .core.parallel_config import get_rank, get_world_size, rank0
 logger = logging.getLogger("api_server")
 
 
+def _hard_exit(code: int):
+    """End the process without unwinding: other threads may be blocked in a collective."""
+    import os
+    import sys
+    logging.shutdown()
+    sys.stdout.flush()
+    sys.stderr.flush()
+    time.sleep(0.5)          # let the event loop write the error responses that were just queued
+    os._exit(code)
+
+
 class _Request:
     __slots__ = ("on_done", "seq")
 
@@ -49,10 +60,16 @@ class EngineLoop:
         self._running = False
         self._thread: Optional[threading.Thread] = None
         self.steps = 0
+        self.fatal: Optional[BaseException] = None
+        # what ends the process after a failure the ranks cannot recover from together (a
+        # supervisor starts a fresh one); tests put a recorder here
+        self.exit_process: Callable[[int], None] = _hard_exit
 
     # ---- called from any thread
     def submit(self, prompt: str, max_tokens: int, temperature: float, top_p: float,
                on_token: Optional[Callable] = None, on_done: Optional[Callable] = None) -> int:
+        if self.fatal is not None:
+            raise RuntimeError(f"the engine stopped after an unrecoverable failure: {self.fatal!r}")
         req = _Request(on_done)
         with self._lock:
             # raises ValueError for a request that can never be scheduled (the handlers answer 400)
@@ -109,9 +126,18 @@ class EngineLoop:
                 logger.exception("step failed")
                 if get_world_size() > 1:
                     # the other ranks are inside the same step and expect its second message: there
-                    # is no way back into lockstep from here
-                    raise
-                self._fail(ctx.sequences, e)
+                    # is no way back into lockstep from here.  Every open request is answered with
+                    # the error and the process ends non-zero (the followers, blocked in their
+                    # receive, go down with the process group; a supervisor starts all ranks afresh)
+                    self._fatal(e)
+                    return
+                starved = getattr(e, "seq_ids", None)
+                if starved is not None:
+                    # a decode step found no page for some sequences and undid itself: only those
+                    # fail, the rest of the batch is scheduled again as if the step had not been tried
+                    self._fail([s for s in ctx.sequences if s.seq_id in set(starved)], e)
+                else:
+                    self._fail(ctx.sequences, e)
                 continue
             ctx.broadcast()
             with self._lock:
@@ -143,6 +169,21 @@ class EngineLoop:
                 self.engine.scheduler.mark_finished(seq)
             self.engine.scheduler.get_finished_results()
         self._report(sequences, error)
+
+    def _fatal(self, error):
+        self.fatal = error
+        self._running = False
+        with self._lock:
+            open_ids = list(self._requests)
+        for seq_id in open_ids:
+            req = self._requests.pop(seq_id, None)
+            self.engine.unregister_stream_callback(seq_id)
+            if req is not None and req.on_done is not None:
+                try:
+                    req.on_done(req.seq, error)
+                except Exception:
+                    logger.exception("reporting the failure of request %s", seq_id)
+        self.exit_process(1)
 
     def run_follower(self):
         """api_server.py:79-90: receive the step, run it, receive the tokens, apply them."""

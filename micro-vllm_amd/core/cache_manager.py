@@ -135,6 +135,22 @@ class KVCacheManager:
               f"(blocks={blocks}, used={used}, block_size={self.block_size})")
         return -1
 
+    def unappend(self, seq_id: int, slot: int):
+        """Take back the `append` that returned `slot` (the step it was made for will not run):
+        a page opened by it goes back to the head of the free list, otherwise the page's fill
+        count drops by one."""
+        blocks = self._blocks.get(seq_id)
+        if not blocks or slot < 0:
+            return
+        last = blocks[-1]
+        assert slot // self.block_size == last, "not this sequence's latest slot"
+        if slot % self.block_size == 0 and self._pos.get(last) == 1 and len(blocks) > 1:
+            blocks.pop()
+            self._pos.pop(last, None)
+            self._free.appendleft(last)
+        else:
+            self._pos[last] -= 1
+
     def clear_slots(self, seq_ids: list, positions: list):
         """Zero the K and V rows (every layer, every kv head) at token index positions[i] of sequence
         seq_ids[i].  Pages are recycled without being cleared, so a slot that the position numbering

@@ -25,6 +25,15 @@ logger = logging.getLogger("InferenceEngine")
 
 
 @dataclass
+
+class KVPoolExhausted(RuntimeError):
+    """A decode step could not get a KV slot for `seq_ids`; nothing of the step was run and the other
+    sequences of the batch are as they were before it."""
+
+    def __init__(self, seq_ids):
+        super().__init__("OOM: no free KV page for sequence(s) %s" % ", ".join(str(i) for i in seq_ids))
+        self.seq_ids = list(seq_ids)
+
 class InferenceStats:
     prep_time: float = 0.0
     gpu_time: float = 0.0
@@ -271,9 +280,19 @@ class InferenceEngine:
             ids_host[i] = seq.get_next_input_ids()[0]
         input_ids = ids_host[:batch_size].to(device, non_blocking=True)
         all_greedy = all(seq.temperature <= 0 for seq in batch)
+        taken, starved = [], []
         for i, seq in enumerate(batch):
-            if first[i] and self.cache_manager.append(seq.seq_id) == -1:
-                raise RuntimeError("OOM")
+            if first[i]:
+                slot = self.cache_manager.append(seq.seq_id)
+                (starved if slot == -1 else taken).append((seq.seq_id, slot))
+        if starved:
+            # the step will not run: the sequences that did get a slot give it back, so that they
+            # can take part in the next step as if this one had not been tried, and the caller
+            # learns which sequences the pool had no page for (the reference fails the whole batch
+            # and leaves the others one slot ahead, core/engine.py:262-266)
+            for sid, slot in reversed(taken):
+                self.cache_manager.unappend(sid, slot)
+            raise KVPoolExhausted([sid for sid, _ in starved])
         if self.clear_unwritten_slot:
             # first decode step of a sequence (one token generated so far, by prefill): index
             # current_position - 1 has never been written and is attended from now on

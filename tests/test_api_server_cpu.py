@@ -131,6 +131,68 @@ def test_a_failing_step_fails_its_requests_and_the_loop_goes_on():
         loop.stop()
 
 
+def test_a_decode_step_without_pages_fails_only_the_starved_sequence():
+    """A decode step that found no KV page for one sequence undoes itself (KVPoolExhausted names the
+    sequence): that request fails, the other of the same batch finishes with the tokens it would have
+    had anyway."""
+    from starlette.testclient import TestClient
+
+    from micro_vllm_amd.core.engine import KVPoolExhausted
+
+    class Starving(RuleEngine):
+        def step(self, ctx):
+            if ctx.batch_type == "decode":
+                hit = [s.seq_id for s in ctx.sequences if "starve" in s.prompt]
+                if hit:
+                    raise KVPoolExhausted(hit)
+            return super().step(ctx)
+
+    eng = Starving()
+    loop = EngineLoop(eng)
+    loop.start()
+    try:
+        with TestClient(create_app(loop)) as c:
+            import concurrent.futures as cf
+            with cf.ThreadPoolExecutor(2) as ex:
+                bad = ex.submit(lambda: c.post("/generate", json={"prompt": "starve me", "max_tokens": 6}))
+                good = ex.submit(lambda: c.post("/generate", json={"prompt": "feed me", "max_tokens": 6}))
+                bad, good = bad.result(), good.result()
+            assert bad.status_code == 500 and "OOM" in bad.text
+            ids, out = expected("feed me", 6)
+            assert good.json()["text"] == Tok().decode(ids + out)
+            assert c.get("/health").json()["running_sequences"] == 0 and not loop._requests
+    finally:
+        loop.stop()
+
+
+def test_with_several_ranks_a_failing_step_answers_every_request_and_ends_the_process(monkeypatch):
+    """Rank 0 of a group cannot get the other ranks back into step after a failed step: every open
+    request gets the error, new ones are refused, and the process is told to exit non-zero."""
+    import time
+
+    import micro_vllm_amd.api_server as srv
+
+    monkeypatch.setattr(srv, "get_world_size", lambda: 2)
+    monkeypatch.setattr(srv.BatchInferenceContext, "broadcast", lambda self: None)
+    eng = RuleEngine(fail_on="boom")
+    loop = EngineLoop(eng)
+    exits, done = [], []
+    loop.exit_process = exits.append
+    loop.submit("a boom prompt", 4, 0.0, 1.0, on_done=lambda seq, err: done.append(("boom", err)))
+    loop.submit("an innocent one that is much longer and sits in another bucket " * 4, 4, 0.0, 1.0,
+                on_done=lambda seq, err: done.append(("other", err)))
+    loop.start()
+    t0 = time.time()
+    while not exits and time.time() - t0 < 10:
+        time.sleep(0.01)
+    loop.stop()
+    assert exits == [1]
+    assert sorted(k for k, _ in done) == ["boom", "other"] and all(isinstance(e, RuntimeError) for _, e in done)
+    assert not loop._requests
+    with pytest.raises(RuntimeError, match="unrecoverable"):
+        loop.submit("late", 2, 0.0, 1.0)
+
+
 def test_load_generator_against_a_live_server():
     """The load generator over real sockets: uvicorn in a thread, aiohttp client."""
     import socket

@@ -69,3 +69,31 @@ def test_oom_and_table_width(mv):
     mgr.alloc(2, 5)
     mgr.cache_batch_data([2], [5])
     assert mgr._block_table_buffer.data_ptr() == a  # static address
+
+
+def test_unappend_restores_the_state_before_the_append(mv):
+    """A decode step that is not run after all gives its slots back: inside a page the fill count
+    drops, across a page boundary the page returns to the head of the free list, and the next
+    append hands out the same slot again."""
+    import copy
+
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+
+    mgr = KVCacheManager(6, 16, 1, 1, 8, dtype=torch.float32, device="cpu", max_tokens=64, max_batch_size=2)
+    assert mgr.alloc(1, 13)[0] and mgr.alloc(2, 20)[0]
+    for _ in range(40):                      # crosses page boundaries of both sequences
+        before = (copy.deepcopy(mgr._blocks), dict(mgr._pos), list(mgr._free))
+        s1 = mgr.append(1)
+        if s1 == -1:
+            break
+        s2 = mgr.append(2)
+        if s2 == -1:                         # sequence 2 starved: sequence 1 gives its slot back
+            mgr.unappend(1, s1)
+            assert (mgr._blocks, dict(mgr._pos), list(mgr._free)) == before
+            break
+        mgr.unappend(2, s2)
+        mgr.unappend(1, s1)
+        assert (mgr._blocks, dict(mgr._pos), list(mgr._free)) == before
+        assert (mgr.append(1), mgr.append(2)) == (s1, s2)
+    else:
+        raise AssertionError("the pool never ran out")
