@@ -102,10 +102,15 @@ enum {
                            y is [M, N/2] = swiglu(bf16(x @ W^T)), i.e. the matmul
                            + swiglu_gemm pair of model_graph.py:183-184 in one pass */
     MV_GEMM_OUT_F32 = 2, /* y is fp32 [M,N]: the un-rounded accumulators (tests) */
-    MV_GEMM_SLABS = 4    /* y is not written (may be NULL): the product is left in `workspace` as
+    MV_GEMM_SLABS = 4,   /* y is not written (may be NULL): the product is left in `workspace` as
                             mv_wgemm_slab_count(m, n, k) fp32 slabs [slab][M][N] whose sum, added in
                             slab order, is x @ W^T - for a caller whose next kernel adds them
                             (mv_allreduce_addnorm).  Workspace: mv_wgemm_postnorm_workspace_bytes. */
+    MV_GEMM_PLAN_SLABS = 8 /* an ordinary call (y written, epilogue applied) that cuts k exactly as the
+                            MV_GEMM_SLABS call of the same shape does, so that its sums are formed in
+                            the same order: what a step built from separate kernels uses where the
+                            fused step hands slabs to the next kernel (tests compare the two bit
+                            for bit) */
 };
 int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
              const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n, int k,

@@ -22,6 +22,7 @@ MV_GEMM_DEFAULT = 0
 MV_GEMM_SWIGLU = 1
 MV_GEMM_OUT_F32 = 2
 MV_GEMM_SLABS = 4
+MV_GEMM_PLAN_SLABS = 8
 MV_NORM_VAR_FROM_ROUNDED = 1
 
 class ChainPhase(ctypes.Structure):

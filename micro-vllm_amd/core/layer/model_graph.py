@@ -215,10 +215,13 @@ class ModelGraphRunner:
         need = 0
         shapes = [(qkv_dim, self.hidden_dim), (o_dim, _b.attn._o.k), (_b.mlp._gu.n, self.hidden_dim),
                   (self.hidden_dim, _b.mlp._d.k), (self.vocab_size, self.hidden_dim)]
+        # (over every batch size: fewer rows may be cut into more k-slices)
         for n, k in shapes:
-            need = max(need, L.mv_wgemm_workspace_bytes(max_b, n, k))
-        for k in (_b.attn._o.k, _b.mlp._d.k):  # projections whose slab reduction carries a norm
-            need = max(need, L.mv_wgemm_postnorm_workspace_bytes(max_b, self.hidden_dim, k))
+            need = max([need] + [L.mv_wgemm_workspace_bytes(m, n, k) for m in range(1, max_b + 1)])
+        # projections that hand k-slabs to the kernel after them: O and down (their slab reduction
+        # carries a norm, or is the tensor-parallel reduction)
+        for n, k in ((self.hidden_dim, _b.attn._o.k), (self.hidden_dim, _b.mlp._d.k)):
+            need = max([need] + [L.mv_wgemm_postnorm_workspace_bytes(m, n, k) for m in range(1, max_b + 1)])
         self._gemm_ws = gemm_workspace(dev, max(need, 16))
         self._attn_ws = None
         # arrival counter of the chained projections' grid barrier (zero-initialised, never reset)
@@ -280,7 +283,9 @@ class ModelGraphRunner:
             self.attention._sin_pool, num_splits=self._splits_for(bs, cache_manager),
             out=self._attn[:bs], workspace=self._attn_ws)
         out_buf = self._attn_out[:bs]
-        wgemm(attn.reshape(bs, -1), block.attn._o, out_buf, workspace=self._gemm_ws)
+        # bs > 4: k cut as in the batched step, whose O and down projections hand k-slabs to the
+        # kernel that follows them (same sums, bit for bit)
+        wgemm(attn.reshape(bs, -1), block.attn._o, out_buf, workspace=self._gemm_ws, plan_slabs=bs > 4)
         return out_buf
 
     def _ffn(self, x_normed, block, bs, residual=None):
@@ -290,7 +295,7 @@ class ModelGraphRunner:
             wgemm(x_normed, block.mlp._gu, self._gate_up[:bs], workspace=self._gemm_ws)
             swiglu_gemm(self._gate_up[:bs], self._swiglu_out[:bs])
         wgemm(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs], residual=residual,
-              workspace=self._gemm_ws)
+              workspace=self._gemm_ws, plan_slabs=bs > 4)
         return self._mlp_out[:bs]
 
     # ------------------------------------------------------------------ decode

@@ -23,6 +23,8 @@
 // t = bf16(t + bias); t = bf16(t + residual); SWIGLU: out = bf16(silu(gate_t) * up_t).
 #include "common.h"
 
+#include <algorithm>
+
 #include <atomic>
 
 namespace mv {
@@ -727,7 +729,7 @@ int launch_wgemm_finalize(float* partial, int ksplit, int m, int n, int flags, c
 // ------------------------------------------------------------ host planning
 // k-slices per strip: balance whole units over the CUs.  Cost in tiles per CU,
 // with a split paying roughly one extra kernel boundary.
-static int mfma_strip_group(int m, int nt, int kt);
+static int mfma_strip_group(int m, int nt, int kt, bool free_reduce);
 
 // k-slices for `units` whole-k work items: split while fewer than half the CUs would have one and
 // every wave keeps at least 4 tiles
@@ -744,9 +746,11 @@ static int ksplit_for_units(int units, int kt) {
 }
 
 // `nt` = work items along N: strips for the dot form, strip groups for the MFMA form.
-static int pick_ksplit(int m, int nt, int kt) {
+// `free_reduce`: the slabs are added by a launch that runs anyway (the caller's next kernel for
+// MV_GEMM_SLABS, the norm kernel of mv_wgemm_postnorm), so a k-split costs no launch of its own.
+static int pick_ksplit(int m, int nt, int kt, bool free_reduce = false) {
     if (m > 4) {
-        const int sg = mfma_strip_group(m, nt, kt);
+        const int sg = mfma_strip_group(m, nt, kt, free_reduce);
         nt = (nt + sg - 1) / sg;
     }
     if (const int forced = g_tune_ksplit; forced > 0) {
@@ -822,10 +826,11 @@ static int launch_mfma(const GemmArgs& a, int grid, hipStream_t s) {
 
 // strips per workgroup of the MFMA form: the cross-wave reduction buffer is 8 KiB per
 // (strip, row block) pair, 128 KiB for four strips of four row blocks
-static int mfma_strip_group(int m, int nt, int kt) {
+static int mfma_strip_group(int m, int nt, int kt, bool free_reduce) {
     const int mb = (m + 15) / 16;
     const int most = 4;
-    if (const int forced = g_tune_sg; forced == 1 || forced == 2 || forced == 4 || (forced == 7 && mb <= 2))
+    if (const int forced = g_tune_sg;
+        forced == 1 || forced == 2 || forced == 4 || ((forced == 7 || forced == 3) && mb <= 2))
         return forced;
     // Seven strips per workgroup where that deals the strips out to the CUs exactly (Llama-3-8B
     // gate/up: 1792 strips = 7 x 256): in groups of four 448 units fall on 256 CUs as two rounds, the
@@ -841,7 +846,7 @@ static int mfma_strip_group(int m, int nt, int kt) {
     // pairs against 18.2 us with groups of four in two k-slices, 14.1 against 16.0 at M = 24; at
     // M = 48 the two are equal and at M = 64 the x traffic of pairs costs more than the split:
     // 23.1 against 21.8 us)
-    if (mb == 2) return ((nt + most - 1) / most < want && (nt + 1) / 2 >= want) ? 2 : most;
+    if (mb == 2 && !free_reduce) return ((nt + most - 1) / most < want && (nt + 1) / 2 >= want) ? 2 : most;
     if (mb > 2) return most;
     // One row block (5-16 rows).  A small model of the three costs, fitted to the Llama-3-8B
     // projections at 8 and 16 rows (tools/bench_mfma_gemv.py): weights stream at 6.45 MB/us over
@@ -850,16 +855,20 @@ static int mfma_strip_group(int m, int nt, int kt) {
     // strips win at 8 rows, 21.6 against 22.8 us, and lose at 16, 27.3 against 22.9, because x is
     // then as many bytes as the weights; the 4096-wide O projection keeps single strips at both,
     // 9.1 against 11.2 us, its split costing more than its x.)
+    // With a free slab reduction (either row-block count) the same model decides, groups of three
+    // included: the Llama-3-8B QKV projection at 17-32 rows is 128 groups of three in two k-slices,
+    // one unit per CU, where pairs leave a quarter of the CUs without work.
     const int cus = num_cus();
     int best = 1;
     double best_us = 1e30;
-    for (int sg = most; sg >= 1; sg >>= 1) {
+    for (int sg = most; sg >= 1; --sg) {
+        if (sg == 3 && !free_reduce) continue;
         const int groups = (nt + sg - 1) / sg;
         const int ks = ksplit_for_units(groups, kt);
         const long units = (long)groups * ks;
         const double fill = (double)units / (double)(((units + cus - 1) / cus) * cus);
         const double w_mb = (double)nt * kt * 1024e-6, x_mb = (double)units * m * (kt / ks) * 64e-6;
-        const double us = w_mb / (6.45 * fill) + x_mb / 12.9 + (ks > 1 ? 4.7 : 0.0);
+        const double us = w_mb / (6.45 * fill) + x_mb / 12.9 + (ks > 1 && !free_reduce ? 4.7 : 0.0);
         if (us < best_us) {
             best_us = us;
             best = sg;
@@ -921,7 +930,8 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     a.eps = eps;
     a.sum_out = (uint16_t*)sum_out;
     a.ld_sum_out = ld_sum_out;
-    a.ksplit = pick_ksplit(m, a.nt, a.kt);
+    const bool free_reduce = slabs_only || post_ln_w != nullptr || (flags & MV_GEMM_PLAN_SLABS) != 0;
+    a.ksplit = pick_ksplit(m, a.nt, a.kt, free_reduce);
     a.partial = nullptr;
     a.post_ln_w = (const uint16_t*)post_ln_w;
     a.post_out = (uint16_t*)post_out;
@@ -955,7 +965,7 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
     }
     a.ktps = a.kt / a.ksplit;
     a.contig = g_tune_contig;
-    const int sg = m > 4 ? mfma_strip_group(m, a.nt, a.kt) : 1;
+    const int sg = m > 4 ? mfma_strip_group(m, a.nt, a.kt, free_reduce) : 1;
     a.nunits = ((a.nt + sg - 1) / sg) * a.ksplit;
     a.flags = flags;
 
@@ -988,8 +998,8 @@ static int wgemm_impl(const void* x, int64_t ldx, const void* add_r, int64_t ld_
         case 4: rc = launch_dot_waves<4>(a, waves, grid, s); break;
         default: {
             const int mb = (m + 15) / 16;
-            if (mb == 1) rc = sg == 7 ? launch_mfma<1, 7>(a, grid, s) : sg == 4 ? launch_mfma<1, 4>(a, grid, s) : sg == 2 ? launch_mfma<1, 2>(a, grid, s) : launch_mfma<1, 1>(a, grid, s);
-            else if (mb == 2) rc = sg == 7 ? launch_mfma<2, 7>(a, grid, s) : sg == 4 ? launch_mfma<2, 4>(a, grid, s) : sg == 2 ? launch_mfma<2, 2>(a, grid, s) : launch_mfma<2, 1>(a, grid, s);
+            if (mb == 1) rc = sg == 7 ? launch_mfma<1, 7>(a, grid, s) : sg == 3 ? launch_mfma<1, 3>(a, grid, s) : sg == 4 ? launch_mfma<1, 4>(a, grid, s) : sg == 2 ? launch_mfma<1, 2>(a, grid, s) : launch_mfma<1, 1>(a, grid, s);
+            else if (mb == 2) rc = sg == 7 ? launch_mfma<2, 7>(a, grid, s) : sg == 3 ? launch_mfma<2, 3>(a, grid, s) : sg == 4 ? launch_mfma<2, 4>(a, grid, s) : sg == 2 ? launch_mfma<2, 2>(a, grid, s) : launch_mfma<2, 1>(a, grid, s);
             else if (mb == 3) rc = sg == 4 ? launch_mfma<3, 4>(a, grid, s) : sg == 2 ? launch_mfma<3, 2>(a, grid, s) : launch_mfma<3, 1>(a, grid, s);
             else rc = sg == 4 ? launch_mfma<4, 4>(a, grid, s) : sg == 2 ? launch_mfma<4, 2>(a, grid, s) : launch_mfma<4, 1>(a, grid, s);
         }
@@ -1014,13 +1024,13 @@ extern "C" {
 
 // Tuning hook for experiments: key 0 = workgroups per CU, key 1 = forced ksplit,
 // key 2 = waves per workgroup of the dot form (8 or 16), key 3 = strips per workgroup of the
-// MFMA form (1, 2, 4, 7); 0 = let the planner choose.
+// MFMA form (1, 2, 3, 4, 7); 0 = let the planner choose.
 int mv_wgemm_tune(int key, int value) {
     if (key == 2 && (value == 0 || value == 8 || value == 16)) {
         mv::g_tune_waves = value;
         return MV_OK;
     }
-    if (key == 3 && (value == 0 || value == 1 || value == 2 || value == 4 || value == 7)) {
+    if (key == 3 && (value == 0 || value == 1 || value == 2 || value == 3 || value == 4 || value == 7)) {
         mv::g_tune_sg = value;
         return MV_OK;
     }
@@ -1043,7 +1053,8 @@ size_t mv_wgemm_workspace_bytes(int m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
     // slabs for the split the planner picks now; a call that later finds the
     // workspace too small (tuning changed) runs unsplit instead of failing
-    const int ks = mv::pick_ksplit(m, n / 16, k / 32);
+    // (the larger of the plain plan and the MV_GEMM_PLAN_SLABS one: the flag is not known here)
+    const int ks = std::max(mv::pick_ksplit(m, n / 16, k / 32), mv::pick_ksplit(m, n / 16, k / 32, true));
     return ks > 1 ? (size_t)ks * (size_t)m * (size_t)n * sizeof(float) : 0;
 }
 
@@ -1057,12 +1068,12 @@ int mv_wgemm(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
 
 int mv_wgemm_slab_count(int m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
-    return mv::pick_ksplit(m, n / 16, k / 32);
+    return mv::pick_ksplit(m, n / 16, k / 32, true);
 }
 
 size_t mv_wgemm_postnorm_workspace_bytes(int m, int n, int k) {
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) || (k % 32)) return 0;
-    const int ks = mv::pick_ksplit(m, n / 16, k / 32);
+    const int ks = mv::pick_ksplit(m, n / 16, k / 32, true);
     return (size_t)(ks > 1 ? ks : 1) * (size_t)m * (size_t)n * sizeof(float);
 }
 

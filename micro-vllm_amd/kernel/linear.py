@@ -70,11 +70,14 @@ def gemm_workspace(device, nbytes: int) -> Optional[torch.Tensor]:
 
 def wgemm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
           bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-          swiglu: bool = False, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+          swiglu: bool = False, workspace: Optional[torch.Tensor] = None,
+          plan_slabs: bool = False) -> torch.Tensor:
     """out = x @ W^T (+ bias) (+ residual), or swiglu(x @ W^T) when `swiglu`.
 
     x: [M,K] bf16, out: [M,N] bf16 (or fp32 for the un-rounded accumulators), M <= 64.
     Every optional term rounds to bf16 where the reference's separate ops round.
+    `plan_slabs`: cut k as `wgemm_slabs` / `wgemm_postnorm` cut it for this shape (same sums, bit
+    for bit, as the fused step that hands slabs to its next kernel).
     """
     assert x.is_cuda and out.is_cuda and x.dtype == torch.bfloat16
     assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
@@ -88,6 +91,8 @@ def wgemm(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
         flags |= nv.MV_GEMM_OUT_F32
     else:
         assert out.dtype == torch.bfloat16
+    if plan_slabs:
+        flags |= nv.MV_GEMM_PLAN_SLABS
     if bias is not None:
         assert bias.dtype == torch.bfloat16 and bias.numel() == w.n and bias.is_contiguous()
     ld_res = 0

@@ -218,20 +218,20 @@ def test_wgemm_postnorm_is_bit_identical_to_separate_kernels(mv, m, n, k):
 
     # matmul -> rmsnorm_residual_gemm(y, r): sum = bf16(y + r), variance from the unrounded y + r
     for b in (None, bias):
-        y = wgemm(x, sw, new(), bias=b)
+        y = wgemm(x, sw, new(), bias=b, plan_slabs=True)    # k cut as the slab forms cut it
         n2, s2 = new(), new()
         rmsnorm_residual_gemm(y, r, lw, n2, s2, eps)
         s1, n1 = new(), new()
         wgemm_postnorm(x, sw, s1, lw, eps, n1, bias=b, residual=r)
         assert torch.equal(s1, s2) and torch.equal(n1, n2), f"add+norm m={m} bias={b is not None}"
     # matmul with residual epilogue -> rmsnorm_ of the stored hidden state
-    h2 = wgemm(x, sw, new(), residual=r)
+    h2 = wgemm(x, sw, new(), residual=r, plan_slabs=True)
     n2 = rmsnorm_(h2, lw, new(), eps)
     h1, n1 = new(), new()
     wgemm_postnorm(x, sw, h1, lw, eps, n1, residual=r, var_from_rounded=True)
     assert torch.equal(h1, h2) and torch.equal(n1, n2), f"residual then norm m={m}"
     # no residual at all: norm of the projection
-    y2 = wgemm(x, sw, new())
+    y2 = wgemm(x, sw, new(), plan_slabs=True)
     n2 = rmsnorm_(y2, lw, new(), eps)
     y1, n1 = new(), new()
     wgemm_postnorm(x, sw, y1, lw, eps, n1)
