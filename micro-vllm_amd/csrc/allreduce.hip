@@ -60,7 +60,23 @@ struct ArArgs {
     uint16_t* normed;
     int64_t ld_normed;
     int var_from_rounded;
+    int fences;                         // full system-scope fences around the exchange (see the kernel)
 };
+
+// 16 bytes to / from an exchange buffer at system scope: two 8-byte relaxed atomics, which the
+// compiler emits as sc0 sc1 accesses - stores write through to the destination, loads are served from
+// it - so that neither side depends on a cache being written back or invalidated.
+__device__ __forceinline__ void st16_system(void* p, uint4 v) {
+    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+    __hip_atomic_store(q, ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(q + 1, ((unsigned long long)v.w << 32) | v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ uint4 ld16_system(const void* p) {
+    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+    const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+}
 
 __device__ __forceinline__ size_t ar_data_off(const ArArgs& a, int slot, int src, int row) {
     return kArFlagBytes + (((size_t)slot * a.world + src) * a.max_rows + row) * (size_t)a.max_n * 2;
@@ -107,15 +123,23 @@ __global__ __launch_bounds__(kArThreads) void allreduce_addnorm_kernel(ArArgs a)
 #pragma unroll
         for (int j = 0; j < kArChunks; ++j) {
             const int c = tid + j * kArThreads;
-            if (c < nvec) st16(dst + (size_t)c * 16, mine[j]);
+            if (c < nvec) st16_system(dst + (size_t)c * 16, mine[j]);
         }
     }
-    // every thread's stores are performed system-wide before the flags go up
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    // Every thread's stores are performed system-wide before the flags go up.  The stores are
+    // write-through (system scope) to uncached memory, so "performed" is what the wait for their
+    // acknowledgements gives; a release FENCE would in addition write back every dirty line of this
+    // XCD's L2 (KV rows, projection outputs: none of it the peers' business) and costs 1.5-2 us per
+    // reduction.  `fences` (MVLLM_ALLREDUCE_FENCES=1) keeps the full fences for a platform where
+    // the exchange memory turns out to be cached.
+    if (a.fences)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid < a.world) {
         unsigned int* f = reinterpret_cast<unsigned int*>(a.peers[tid]) + row * kArFlagStride + a.rank;
-        __hip_atomic_store(f, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(f, e, a.fences ? __ATOMIC_RELEASE : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // ---- wait: thread q watches the flag rank q raises here ----------------------------------
         const unsigned int* mf = reinterpret_cast<const unsigned int*>(a.peers[a.rank]) + row * kArFlagStride + tid;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
@@ -130,24 +154,44 @@ __global__ __launch_bounds__(kArThreads) void allreduce_addnorm_kernel(ArArgs a)
         }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    // the partials are read with system-scope loads (never from a cache): no invalidate needed
+    if (a.fences)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else
+        asm volatile("" ::: "memory");
 
     // ---- sum in rank order, then the epilogue of a row-parallel projection + the next norm ------
     const unsigned char* own = a.peers[a.rank];
     uint4 keep[kArChunks];
     float ss = 0.f;
+    // all partials of this thread's chunks are requested before the first is used: one round trip
+    // to the buffer, not one per rank (chunk rows and ranks that do not exist are skipped: uniform)
+    uint4 part[kArChunks][kArMaxWorld];
+#pragma unroll
+    for (int j = 0; j < kArChunks; ++j) {
+        if (j * kArThreads >= nvec) break;
+        const int c = min(tid + j * kArThreads, nvec - 1);
+#pragma unroll
+        for (int q = 0; q < kArMaxWorld; ++q) {
+            if (q >= a.world) break;
+            part[j][q] = ld16_system(own + ar_data_off(a, slot, q, row) + (size_t)c * 16);
+        }
+    }
 #pragma unroll
     for (int j = 0; j < kArChunks; ++j) {
         const int c = tid + j * kArThreads;
         if (c < nvec) {
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            for (int q = 0; q < a.world; ++q) {
-                const uint4 v = ld16(own + ar_data_off(a, slot, q, row) + (size_t)c * 16);
-                const uint32_t v4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    acc[2 * k] += bf16_lo(v4[k]);
-                    acc[2 * k + 1] += bf16_hi(v4[k]);
+            for (int q = 0; q < kArMaxWorld; ++q) {
+                if (q < a.world) {   // uniform
+                    const uint4 v = part[j][q];
+                    const uint32_t v4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        acc[2 * k] += bf16_lo(v4[k]);
+                        acc[2 * k + 1] += bf16_hi(v4[k]);
+                    }
                 }
             }
             const uint32_t r4[4] = {r_in[j].x, r_in[j].y, r_in[j].z, r_in[j].w};
@@ -205,6 +249,7 @@ struct ArComm {
     int* status = nullptr;
     unsigned long long timeout_ticks = 0;
     bool connected = false;
+    bool fences = false;   // MVLLM_ALLREDUCE_FENCES=1
 };
 
 static int ar_fail(hipError_t e) {
@@ -272,6 +317,7 @@ int mv_allreduce_init(int rank, int world, int max_rows, int max_n, void** comm_
         if (v > 0.0) ms = v;
     }
     c->timeout_ticks = (unsigned long long)(ms * 1.0e5);   // 100 MHz
+    if (const char* f = getenv("MVLLM_ALLREDUCE_FENCES")) c->fences = atoi(f) != 0;
     c->connected = (world == 1);
     *comm_out = c;
     return MV_OK;
@@ -358,6 +404,7 @@ int mv_allreduce_addnorm(void* comm, const void* in, int64_t ld_in, const float*
     a.epoch = c->epoch;
     a.status = c->status;
     a.timeout_ticks = c->timeout_ticks;
+    a.fences = c->fences ? 1 : 0;
     a.in = (const uint16_t*)in;
     a.ld_in = ld_in;
     a.slabs = slabs;
