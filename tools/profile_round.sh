@@ -18,4 +18,10 @@ for BS in 1 32; do
     run timeout -s KILL 300 rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc_${C}_bs$BS" -o p -- python3 "$ROOT/bench.py" --bs $BS $SHORT > "$OUT/pmc_${C}_bs$BS.json" 2> "$OUT/pmc_${C}_bs$BS.err"
   done
 done
+# matrix-pipe counters of the prefill kernels (one pass; SQ_VALU_MFMA_BUSY_CYCLES counts cycles,
+# SQ_BUSY_CYCLES and SQ_WAVE_CYCLES per-SE / quad-cycle units: tools/pmc_summary.py prints the sums)
+run timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_mfma_gemm" -o p -- python3 "$ROOT/tools/bench_gemm_prefill.py" 4096 > "$OUT/pmc_mfma_gemm.log" 2> "$OUT/pmc_mfma_gemm.err"
+run timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_mfma_attn" -o p -- python3 "$ROOT/tools/attn_prefill_only.py" 4096 1 > "$OUT/pmc_mfma_attn.log" 2> "$OUT/pmc_mfma_attn.err"
+python3 "$ROOT/tools/pmc_summary.py" gemm_prefill_wide $(find "$OUT/pmc_mfma_gemm" -name "*counter_collection.csv") > "$OUT/pmc_mfma_gemm_summary.txt"
+python3 "$ROOT/tools/pmc_summary.py" paged_attn_prefill $(find "$OUT/pmc_mfma_attn" -name "*counter_collection.csv") > "$OUT/pmc_mfma_attn_summary.txt"
 ls -R "$OUT" | head -60
