@@ -99,8 +99,24 @@ __global__ __launch_bounds__(kArThreads) void allreduce_addnorm_kernel(ArArgs a)
         const int c = min(tid + j * kArThreads, nvec - 1);   // chunks past the row end re-read the last
         const int n0 = c * 8;
         if (a.slabs) {
+            // the first four slabs are requested before any is added (added in order either way)
+            f32x4_t s_lo[4], s_hi[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks >= a.ksplit) break;   // uniform
+                const float* p = a.slabs + ((int64_t)ks * a.rows + row) * a.n + n0;
+                s_lo[ks] = *reinterpret_cast<const f32x4_t*>(p);
+                s_hi[ks] = *reinterpret_cast<const f32x4_t*>(p + 4);
+            }
             f32x4_t lo = (f32x4_t){0.f, 0.f, 0.f, 0.f}, hi = lo;
-            for (int ks = 0; ks < a.ksplit; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks < a.ksplit) {
+                    lo += s_lo[ks];
+                    hi += s_hi[ks];
+                }
+            }
+            for (int ks = 4; ks < a.ksplit; ++ks) {
                 const float* p = a.slabs + ((int64_t)ks * a.rows + row) * a.n + n0;
                 lo += *reinterpret_cast<const f32x4_t*>(p);
                 hi += *reinterpret_cast<const f32x4_t*>(p + 4);

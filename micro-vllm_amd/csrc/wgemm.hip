@@ -594,9 +594,19 @@ __global__ __launch_bounds__(256) void wgemm_finalize_kernel(GemmArgs a) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * 256) {
         const int m = (int)(i / ncols), c = (int)(i - (int64_t)m * ncols);
+        // all slabs of the element requested before the first is added (they are added in order)
         auto slab_sum = [&](int n) {
+            float v[kMaxKsplit];
+#pragma unroll
+            for (int ks = 0; ks < kMaxKsplit; ++ks) {
+                if (ks >= a.ksplit) break;   // uniform
+                v[ks] = a.partial[((int64_t)ks * a.m + m) * a.n + n];
+            }
             float s = 0.f;
-            for (int ks = 0; ks < a.ksplit; ++ks) s += a.partial[((int64_t)ks * a.m + m) * a.n + n];
+#pragma unroll
+            for (int ks = 0; ks < kMaxKsplit; ++ks)
+                if (ks < a.ksplit) s += v[ks];
+            for (int ks = kMaxKsplit; ks < a.ksplit; ++ks) s += a.partial[((int64_t)ks * a.m + m) * a.n + n];
             return s;
         };
         if (sw) {
@@ -627,17 +637,24 @@ __global__ __launch_bounds__(256) void wgemm_finalize_norm_kernel(GemmArgs a) {
     const int nvec = a.n >> 3;
     uint4 keep[kPostChunks];
     float ss = 0.f;
-    // Every operand of every chunk is requested before the first is used (chunks past the row end
-    // re-read the last one): the slabs were written by another kernel, so each dependent round of
-    // loads is a trip to memory, and this kernel is nothing but such trips.
-    f32x4_t p_lo[kPostChunks], p_hi[kPostChunks];
+    // Every operand of every chunk is requested before the first is used - the first kPostAhead slabs
+    // included (the usual splits are 2 and 4): the slabs were written by another kernel, so each
+    // dependent round of loads is a trip to memory, and this kernel is nothing but such trips.
+    // (Chunk rows and slabs that do not exist are skipped: both conditions are uniform.)
+    constexpr int kPostAhead = 4;
+    f32x4_t p_lo[kPostChunks][kPostAhead], p_hi[kPostChunks][kPostAhead];
     uint4 b_in[kPostChunks], r_in[kPostChunks], w_in[kPostChunks];
 #pragma unroll
     for (int j = 0; j < kPostChunks; ++j) {
+        if (j * 256 >= nvec) break;
         const int n0 = min(threadIdx.x + j * 256, nvec - 1) * 8;
-        const float* p = a.partial + (int64_t)m * a.n + n0;
-        p_lo[j] = *reinterpret_cast<const f32x4_t*>(p);
-        p_hi[j] = *reinterpret_cast<const f32x4_t*>(p + 4);
+#pragma unroll
+        for (int ks = 0; ks < kPostAhead; ++ks) {
+            if (ks >= a.ksplit) break;
+            const float* p = a.partial + ((int64_t)ks * a.m + m) * a.n + n0;
+            p_lo[j][ks] = *reinterpret_cast<const f32x4_t*>(p);
+            p_hi[j][ks] = *reinterpret_cast<const f32x4_t*>(p + 4);
+        }
         b_in[j] = a.bias ? ld16(a.bias + n0) : make_uint4(0, 0, 0, 0);
         r_in[j] = a.residual ? ld16(a.residual + (int64_t)m * a.ld_res + n0) : make_uint4(0, 0, 0, 0);
         w_in[j] = ld16(a.post_ln_w + n0);
@@ -648,9 +665,14 @@ __global__ __launch_bounds__(256) void wgemm_finalize_norm_kernel(GemmArgs a) {
         if (c < nvec) {
             const int n0 = c * 8;
             f32x4_t lo = (f32x4_t){0.f, 0.f, 0.f, 0.f}, hi = lo;
-            lo += p_lo[j];
-            hi += p_hi[j];
-            for (int ks = 1; ks < a.ksplit; ++ks) {
+#pragma unroll
+            for (int ks = 0; ks < kPostAhead; ++ks) {
+                if (ks < a.ksplit) {   // slabs are added in order, whichever way they were fetched
+                    lo += p_lo[j][ks];
+                    hi += p_hi[j][ks];
+                }
+            }
+            for (int ks = kPostAhead; ks < a.ksplit; ++ks) {
                 const float* p = a.partial + ((int64_t)ks * a.m + m) * a.n + n0;
                 lo += *reinterpret_cast<const f32x4_t*>(p);
                 hi += *reinterpret_cast<const f32x4_t*>(p + 4);
