@@ -858,39 +858,29 @@ static int mfma_strip_group(int m, int nt, int kt, bool free_reduce) {
     // gate/up: 1792 strips = 7 x 256): in groups of four 448 units fall on 256 CUs as two rounds, the
     // second three quarters full, and every workgroup re-reads x for four strips instead of seven.
     if (mb <= 2 && nt % 7 == 0 && (nt / 7) % num_cus() == 0) return 7;
-    // From sweeps (tools/sweep_mfma_gemv.py).  Two or more row blocks of x: always the widest
-    // group - the x traffic out of L2 dominates otherwise (M=32, down projection: 41.7 us with
-    // single strips against 25.9 us with groups of four).  One row block: the largest group that
-    // still leaves about one workgroup per CU, because sharing only pays once every CU has work.
-    const int want = num_cus() * 3 / 4;
-    // ... unless groups of two strips fill the chip without a k-split where groups of four do not:
-    // the split costs a second launch that adds the slabs (Llama-3-8B QKV at M = 32: 16.2 us with
-    // pairs against 18.2 us with groups of four in two k-slices, 14.1 against 16.0 at M = 24; at
-    // M = 48 the two are equal and at M = 64 the x traffic of pairs costs more than the split:
-    // 23.1 against 21.8 us)
-    if (mb == 2 && !free_reduce) return ((nt + most - 1) / most < want && (nt + 1) / 2 >= want) ? 2 : most;
+    // Three or four row blocks of x: always the widest group - the x traffic out of L2 dominates
+    // otherwise (tools/sweep_mfma_gemv.py).
     if (mb > 2) return most;
-    // One row block (5-16 rows).  A small model of the three costs, fitted to the Llama-3-8B
-    // projections at 8 and 16 rows (tools/bench_mfma_gemv.py): weights stream at 6.45 MB/us over
-    // the CUs that have a unit, every unit re-reads its k-slice of x out of L2 at about 12.9 MB/us,
-    // and a k-split pays a slab-reduction launch of 4.7 us.  (Down projection, 14336 wide: single
+    // One or two row blocks (5-32 rows).  A small model of the three costs, fitted to the Llama-3-8B
+    // projections at 8, 16 and 32 rows (tools/bench_mfma_gemv.py, tools/bench_slabs.py): weights
+    // stream at 6.45 MB/us over the CUs that have a unit, every unit re-reads its k-slice of x out of
+    // L2 at about 12.9 MB/us, and a k-split pays a slab-reduction launch of 3.6 us (QKV at 32 rows:
+    // groups of three in two k-slices, one unit per CU, 11.8 + 3.0 us against 16.2 for pairs without
+    // a split, which leave a quarter of the CUs idle).  (Down projection, 14336 wide: single
     // strips win at 8 rows, 21.6 against 22.8 us, and lose at 16, 27.3 against 22.9, because x is
     // then as many bytes as the weights; the 4096-wide O projection keeps single strips at both,
     // 9.1 against 11.2 us, its split costing more than its x.)
-    // With a free slab reduction (either row-block count) the same model decides, groups of three
-    // included: the Llama-3-8B QKV projection at 17-32 rows is 128 groups of three in two k-slices,
-    // one unit per CU, where pairs leave a quarter of the CUs without work.
+    // With a free slab reduction the same model decides with that term dropped.
     const int cus = num_cus();
     int best = 1;
     double best_us = 1e30;
     for (int sg = most; sg >= 1; --sg) {
-        if (sg == 3 && !free_reduce) continue;
         const int groups = (nt + sg - 1) / sg;
         const int ks = ksplit_for_units(groups, kt);
         const long units = (long)groups * ks;
         const double fill = (double)units / (double)(((units + cus - 1) / cus) * cus);
         const double w_mb = (double)nt * kt * 1024e-6, x_mb = (double)units * m * (kt / ks) * 64e-6;
-        const double us = w_mb / (6.45 * fill) + x_mb / 12.9 + (ks > 1 && !free_reduce ? 4.7 : 0.0);
+        const double us = w_mb / (6.45 * fill) + x_mb / 12.9 + (ks > 1 && !free_reduce ? 3.6 : 0.0);
         if (us < best_us) {
             best_us = us;
             best = sg;
