@@ -18,12 +18,21 @@
 // clamped on load (finite data, masked to zero weight).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace mv {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 constexpr float kPfNegBig = -1.0e30f;
+constexpr int kPfWideFrom = 2048;   // chunk length from which 8-wave workgroups are taken
+// waves per workgroup of the attention kernel forced by MVLLM_PREFILL_ATTN_WAVES (4 or 8; read once)
+static const int g_pf_waves = [] {
+    const char* e = getenv("MVLLM_PREFILL_ATTN_WAVES");
+    const int v = e && *e ? atoi(e) : 0;
+    return v == 4 || v == 8 ? v : 0;
+}();
 
 // ------------------------------------------------------------------ rotate + store
 struct RopeStoreArgs {
@@ -134,21 +143,25 @@ struct PfArgs {
     uint16_t* out;          // [B*S][out_stride]
     int64_t out_stride;
     int B, S, hq, hkv, g;
-    int qt, qt_shift;       // query positions per workgroup = 128 / g
+    int qt, qt_shift;       // query positions per workgroup = (128 or 256) / g
     int nqb;
     int page_shift, num_pages, page;
     float scale_log2;
 };
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
+// NW waves per workgroup = 32 NW stacked query rows against every staged K/V tile: 4 (128 rows, two
+// workgroups per CU) or 8 (256 rows, one per CU: each tile fetched and stored to LDS once for twice
+// the matrix work - taken when that still leaves every CU a workgroup and a half).
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void paged_attn_prefill_kernel(PfArgs a) {
+    constexpr int NT = NW * 64;        // threads
     constexpr int KT = 64;             // keys per LDS tile
     constexpr int KS = D / 32;         // k-steps of K.Q^T
     constexpr int DT = D / 16;         // 16-wide slices of the head dimension
     constexpr int KROW = D * 2 + 16;   // LDS row strides (bytes): conflict-free row reads ...
     constexpr int VROW = D * 2 + 32;   // ... and conflict-free transposed reads
     constexpr int VPR = D / 8;         // 16-byte vectors per row
-    constexpr int NV = KT * VPR / 256; // vectors per thread per tile
+    constexpr int NV = KT * VPR / NT;  // vectors per thread per tile
     __shared__ __attribute__((aligned(16))) unsigned char kL[2][KT * KROW];
     __shared__ __attribute__((aligned(16))) unsigned char vL[2][KT * VROW];
 
@@ -200,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
     auto g_load = [&](uint4(&kr)[NV], uint4(&vr)[NV], int t, int pg) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int v = threadIdx.x + 256 * j, row = v / VPR, ch = v % VPR;
+            const int v = threadIdx.x + NT * j, row = v / VPR, ch = v % VPR;
             const int kp = min(t * KT + row, last_key);
             const int64_t off = (((int64_t)pg * a.page + (kp & (a.page - 1))) * a.hkv + kvh) * D + ch * 8;
             kr[j] = ld16(a.k_cache + off);
@@ -210,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void paged_attn_prefill_kernel(PfArgs a) {
     auto l_store = [&](const uint4(&kr)[NV], const uint4(&vr)[NV], int buf) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
-            const int v = threadIdx.x + 256 * j, row = v / VPR, ch = v % VPR;
+            const int v = threadIdx.x + NT * j, row = v / VPR, ch = v % VPR;
             *reinterpret_cast<uint4*>(&kL[buf][row * KROW + ch * 16]) = kr[j];
             *reinterpret_cast<uint4*>(&vL[buf][row * VROW + ch * 16]) = vr[j];
         }
@@ -482,7 +495,16 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
     a.hq = hq;
     a.hkv = hkv;
     a.g = g;
-    a.qt = 128 / g;
+    // 256-row workgroups for long chunks (measured: 4096 tokens 202 against 220-229 us per layer of
+    // the 8B shape, 8 x 1024 tokens 126 against 121) that give every CU work
+    const int qt8 = 256 / g;
+    const int64_t grid8 = (int64_t)((seq + qt8 - 1) / qt8) * hkv * bs;
+    const int64_t rounds8 = (grid8 + num_cus() - 1) / num_cus();
+    // ... and fill their last round of one workgroup per CU to nine tenths (3072 tokens: 384 workgroups
+    // on 256 CUs, 133 against 121 us)
+    const bool wide = seq >= kPfWideFrom && grid8 * 10 >= rounds8 * num_cus() * 9 && g_pf_waves != 4;
+    a.qt = wide || g_pf_waves == 8 ? qt8 : 128 / g;
+    const bool eight = a.qt == qt8;
     a.qt_shift = __builtin_ctz((unsigned)a.qt);
     a.nqb = (seq + a.qt - 1) / a.qt;
     a.page = page;
@@ -491,12 +513,15 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
     a.scale_log2 = scale * 1.4426950408889634f;
     const int64_t grid = (int64_t)a.nqb * hkv * bs;
     if (grid > 0x7fffffffLL) return MV_ERR_UNSUPPORTED;
-    if (d == 128)
-        hipLaunchKernelGGL(paged_attn_prefill_kernel<128>, dim3((unsigned)grid), dim3(256), 0,
-                           (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 128 && eight)
+        hipLaunchKernelGGL((paged_attn_prefill_kernel<128, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else if (d == 128)
+        hipLaunchKernelGGL((paged_attn_prefill_kernel<128, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);
+    else if (eight)
+        hipLaunchKernelGGL((paged_attn_prefill_kernel<64, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);
     else
-        hipLaunchKernelGGL(paged_attn_prefill_kernel<64>, dim3((unsigned)grid), dim3(256), 0,
-                           (hipStream_t)stream, a);
+        hipLaunchKernelGGL((paged_attn_prefill_kernel<64, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);
     return check_launch();
 }
 
