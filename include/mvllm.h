@@ -318,6 +318,10 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
                           const int32_t* cache_seqlens, const int32_t* block_table, int bt_stride,
                           void* out, int64_t out_stride, int bs, int seq, int hq, int hkv, int d,
                           int page, int num_pages, float scale, mv_stream_t stream);
+/* Waves per workgroup the call above takes for this shape on the current device (4 = 128 stacked query
+ * rows per workgroup, 8 = 256; for tests and tools, no counterpart in the reference;
+ * MVLLM_PREFILL_ATTN_WAVES=4/8 forces one for a process). */
+int mv_paged_attn_prefill_form(int bs, int seq, int hq, int hkv);
 
 /* key[t,h,:] -> k_cache[slot/page, slot%page, h, :] (same for value); slot -1 = skip.
  * key/value: [T,H,D] with token stride kv_stride_t; slot_mapping int32 [T].

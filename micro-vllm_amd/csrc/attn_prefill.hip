@@ -34,6 +34,17 @@ static const int g_pf_waves = [] {
     return v == 4 || v == 8 ? v : 0;
 }();
 
+// 256-row (8-wave) workgroups for long chunks (measured: 4096 tokens 202 against 220-229 us per layer
+// of the 8B shape, 8 x 1024 tokens 126 against 121) that fill their last round of one workgroup per
+// CU to nine tenths (3072 tokens: 384 workgroups on 256 CUs, 133 against 121 us)
+static bool pf_eight_waves(int bs, int seq, int hkv, int g) {
+    if (g_pf_waves) return g_pf_waves == 8;
+    const int qt8 = 256 / g;
+    const int64_t grid8 = (int64_t)((seq + qt8 - 1) / qt8) * hkv * bs;
+    const int64_t rounds8 = (grid8 + num_cus() - 1) / num_cus();
+    return seq >= kPfWideFrom && grid8 * 10 >= rounds8 * num_cus() * 9;
+}
+
 // ------------------------------------------------------------------ rotate + store
 struct RopeStoreArgs {
     uint16_t* qkv;          // [B*S][row_stride]: q heads | k heads | v heads
@@ -462,6 +473,11 @@ int mv_rope_prefill(const void* x, int64_t x_stride, void* y, int64_t y_stride, 
     return check_launch();
 }
 
+int mv_paged_attn_prefill_form(int bs, int seq, int hq, int hkv) {
+    if (bs <= 0 || seq <= 0 || hq <= 0 || hkv <= 0 || hq % hkv) return 0;
+    return mv::pf_eight_waves(bs, seq, hkv, hq / hkv) ? 8 : 4;
+}
+
 int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,
                           const int32_t* cache_seqlens, const int32_t* block_table, int bt_stride,
                           void* out, int64_t out_stride, int bs, int seq, int hq, int hkv, int d,
@@ -495,15 +511,9 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
     a.hq = hq;
     a.hkv = hkv;
     a.g = g;
-    // 256-row workgroups for long chunks (measured: 4096 tokens 202 against 220-229 us per layer of
-    // the 8B shape, 8 x 1024 tokens 126 against 121) that give every CU work
     const int qt8 = 256 / g;
-    const int64_t grid8 = (int64_t)((seq + qt8 - 1) / qt8) * hkv * bs;
-    const int64_t rounds8 = (grid8 + num_cus() - 1) / num_cus();
-    // ... and fill their last round of one workgroup per CU to nine tenths (3072 tokens: 384 workgroups
-    // on 256 CUs, 133 against 121 us)
-    const bool wide = seq >= kPfWideFrom && grid8 * 10 >= rounds8 * num_cus() * 9 && g_pf_waves != 4;
-    a.qt = wide || g_pf_waves == 8 ? qt8 : 128 / g;
+    const bool wide = pf_eight_waves(bs, seq, hkv, g);
+    a.qt = wide ? qt8 : 128 / g;
     const bool eight = a.qt == qt8;
     a.qt_shift = __builtin_ctz((unsigned)a.qt);
     a.nqb = (seq + a.qt - 1) / a.qt;

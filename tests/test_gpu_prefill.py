@@ -101,6 +101,29 @@ def test_prefill_attention_vs_oracle(mv, D, Hq, Hkv, S, starts):
     assert_close_bf16(got, rounded, atol=4e-3, rtol=2 ** -6, what="vs bf16-P oracle")
 
 
+def test_prefill_attention_long_chunks_take_256_row_workgroups(mv):
+    """Chunks of 2048 tokens and more whose 256-row workgroups fill the CUs run eight waves per
+    workgroup (one staged K/V tile against 256 stacked query rows); same bounds as above, non-zero
+    starts included."""
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.core.paged_attention import flash_attn_with_kvcache
+
+    D, Hq, Hkv, S, starts = 64, 8, 4, 2048, [0, 256, 5, 300]
+    assert nv.lib().mv_paged_attn_prefill_form(len(starts), S, Hq, Hkv) == 8, "meant to take the 8-wave form"
+    assert nv.lib().mv_paged_attn_prefill_form(len(starts), 300, Hq, Hkv) == 4
+    q, k, v, kc, vc, bt, st = _paged_case(len(starts), S, Hq, Hkv, D, starts, seed=77, n_pages=44, max_blocks=10)
+    kc1, vc1 = kc.clone(), vc.clone()
+    exact, bound = flash_attn_with_kvcache_ref(q, kc1, vc1, k, v, None, None, st, bt, causal=True,
+                                               p_bf16=False, return_p_bound=True)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    got = flash_attn_with_kvcache(q.to(DEV), kcd, vcd, k=k.to(DEV), v=v.to(DEV),
+                                  cache_seqlens=st.to(DEV), block_table=bt.to(DEV), causal=True).cpu()
+    assert torch.equal(kcd.cpu(), kc1) and torch.equal(vcd.cpu(), vc1)
+    err = (got.float() - exact.float()).abs()
+    tol = 1e-3 + 2 ** -7 * exact.float().abs() + bound
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst excess {(err - tol).max().item():.3e}"
+
+
 def _build(mv, shape, qkv_bias=False, n_blocks=24, max_bs=4, p_bf16=False):
     from micro_vllm_amd.core.cache_manager import KVCacheManager
     from micro_vllm_amd.core.layer.model_graph import ModelGraphRunner
