@@ -21,6 +21,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 namespace mv {
 
 constexpr int kPM = 128;            // rows of x per workgroup
@@ -341,7 +343,9 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     // workgroups resident on the XCD at one time are mband x 32/mband tiles (8 x 4 at 2048 tokens and
     // more) rather than one long column, and the operand rows they pull through that XCD's L2
     // together are as few as 32 tiles allow.
-    const int bid = blockIdx.x;
+    const int tiles = 8 * a.nb_per_xcd * a.mblocks;
+    const int ks = blockIdx.x / tiles, bid = blockIdx.x - ks * tiles;   // k-slice (see the host side), tile
+    const int kt0 = ks * a.ktps, nkt = a.ktps;
     const int xcd = bid & 7, idx = bid >> 3;
     const int per_band = a.mband * a.nb_per_xcd;
     const int band = min(idx / per_band, (a.mblocks - 1) / a.mband);
@@ -353,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     if (nb >= a.nblocks || nbl >= a.nb_per_xcd) return;
     const int m0 = mb * kWM;
     const int ntb = nb * (kWN / 16);
-    const int nstage = a.kt >> 1;
+    const int nstage = nkt >> 1;
 
     // ---- copy sources of this wave: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles likewise.
     // Every copy is addressed as a wave-uniform 64-bit base (scalar registers, advanced by scalar
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     const unsigned char* wbase[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
-        wbase[j] = reinterpret_cast<const unsigned char*>(a.w + (int64_t)min(ntb + 2 * wid + j, a.nt - 1) * a.kt * 64);
+        wbase[j] = reinterpret_cast<const unsigned char*>(a.w + ((int64_t)min(ntb + 2 * wid + j, a.nt - 1) * a.kt + kt0) * 64);
     const unsigned wlane = lane * 16;
     const unsigned char* xbase[2];
     unsigned xlane[4];
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
         const int row = (j & 1) * 8 + (lane >> 3);                          // row of the m-tile
         const int c = (lane & 7) ^ ((row >> 1) & 7);                        // the chunk that lives at position lane & 7
         const int grow = min(m0 + (2 * wid + (j >> 1)) * 16 + row, a.m - 1);
-        if ((j & 1) == 0) xbase[j >> 1] = reinterpret_cast<const unsigned char*>(a.x + (int64_t)first * a.ldx);
+        if ((j & 1) == 0) xbase[j >> 1] = reinterpret_cast<const unsigned char*>(a.x + (int64_t)first * a.ldx + kt0 * 32);
         xlane[j] = (unsigned)(((int64_t)(grow - first) * a.ldx + c * 8) * 2);
     }
     const unsigned x_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xring;
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
                      : : "v"(lane_off), "s"(base), "s"(dst) : "memory");
     };
     auto copy_w = [&](int kt, int slot) {
-        const int ktc = min(kt, a.kt - 1);   // past the end: a harmless re-fetch keeps the counts fixed
+        const int ktc = min(kt, nkt - 1);   // past the end: a harmless re-fetch keeps the counts fixed
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             copy(wbase[j] + (int64_t)ktc * 1024, wlane, w_lds + slot * kWWSlot + (2 * wid + j) * 1024);
@@ -447,13 +451,13 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
             const int st = min((kt >> 1) + 3, nstage - 1), slot = (kt >> 1) % 3;
             copy(xbase[p >> 1] + st * 128, xlane[p], x_lds + slot * kWXSlot + (2 * wid + (p >> 1)) * 2048 + (p & 1) * 1024);
         } else if (p < nx + 2) {
-            const int j = p - nx, ktc = min(kt + 4, a.kt - 1);
+            const int j = p - nx, ktc = min(kt + 4, nkt - 1);
             copy(wbase[j] + (int64_t)ktc * 1024, wlane, w_lds + (kt & 3) * kWWSlot + (2 * wid + j) * 1024);
         }
     };
     auto ktile = [&](bf16x8_t(&wc)[kPNT], bf16x8_t(&xc)[kPMT], bf16x8_t(&wnx)[kPNT], bf16x8_t(&xnx)[kPMT], int kt,
                      bool odd) {
-        const int ktn = min(kt + 1, a.kt - 1);
+        const int ktn = min(kt + 1, nkt - 1);
         const unsigned char* wp = wring + (ktn & 3) * kWWSlot + woff;
         const unsigned char* xp = xring + ((ktn >> 1) % 3) * kWXSlot + ((ktn & 1) ? xoff1 : xoff0);
 #pragma unroll
@@ -485,14 +489,14 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
         __syncthreads();
 #endif
     };
-    for (int kt = 0; kt < a.kt; kt += 2) {   // a.kt is even (k is a multiple of 64)
+    for (int kt = 0; kt < nkt; kt += 2) {   // a slice is a multiple of 64 k (checked on the host)
         ktile(wA, xA, wB, xB, kt, false);
         ktile(wB, xB, wA, xA, kt + 1, true);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after this workgroup is gone
 
     if (ntb + wn * 4 >= a.nt) return;
-    store_wave_tile(a, acc, ntb + wn * 4, m0 + wm * 128, 0, r, q);
+    store_wave_tile(a, acc, ntb + wn * 4, m0 + wm * 128, ks, r, q);
 }
 
 }  // namespace mv
@@ -530,31 +534,43 @@ static int prefill_ksplit(int m, int n, int kt) {
     return best;
 }
 
-// The wide form (256 x 256 tiles, one workgroup per CU) when its tiles fill the chip; MVLLM_PREFILL_WIDE
-// = 0 / 1 forces the choice (read once).
-static bool prefill_wide(int m, int n, int kt) {
+// Which form a product takes and in how many k-slices.  The wide form (256 x 256 tiles, one
+// workgroup per CU) when the 128 x 256 form would not cut k and the wide tiles fill at least half the
+// CUs; and, in TWO k-slices, where its tiles fill three eighths to half of the CUs and k is long (the
+// down projection at 1536-2048 tokens: 96-128 tiles of 224 stages; one workgroup per CU then walks
+// half the stages, and only a long k pays for the 8 bytes per output the slices write and read back
+// plus the reduction launch: 2048 tokens 268 -> 216 us; at 2304 tokens, 144 tiles, 344 against 300).
+// MVLLM_PREFILL_WIDE = 0 / 1 forces the choice of form (read once).
+struct PrefillPlan {
+    bool wide;
+    int ks;
+};
+static PrefillPlan prefill_plan(int m, int n, int kt) {
     static const int forced = [] {
         const char* e = getenv("MVLLM_PREFILL_WIDE");
         return e && *e ? atoi(e) : -1;
     }();
-    if (kt < 8) return false;
-    if (forced >= 0) return forced != 0;
+    const int narrow_ks = prefill_ksplit(m, n, kt);
+    if (kt < 8 || forced == 0) return {false, narrow_ks};
     const long tiles = (long)((m + kWM - 1) / kWM) * ((n + kWN - 1) / kWN);
-    return 2 * tiles >= num_cus();
+    const int cus = num_cus();
+    if (forced < 0 && kt >= 256 && kt % 4 == 0 && 8 * tiles >= 3L * cus && 2 * tiles <= cus) return {true, 2};
+    if (narrow_ks == 1 && (forced == 1 || 2 * tiles >= cus)) return {true, 1};
+    return {false, narrow_ks};
 }
 }  // namespace mv
 
 extern "C" size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k) {
     using namespace mv;
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
-    const int ks = prefill_ksplit(m, n, k / 32);
+    const int ks = prefill_plan(m, n, k / 32).ks;
     return ks > 1 ? (size_t)ks * m * n * sizeof(float) : 0;
 }
 
 extern "C" int mv_gemm_prefill_form(int m, int n, int k) {
     using namespace mv;
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
-    return prefill_ksplit(m, n, k / 32) == 1 && prefill_wide(m, n, k / 32) ? 1 : 0;
+    return prefill_plan(m, n, k / 32).wide ? 1 : 0;
 }
 
 extern "C" int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
@@ -600,17 +616,21 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
     a.nb_per_xcd = (a.nblocks + 7) / 8;
     a.mband = 1;
     a.flags = flags;
-    a.ksplit = prefill_ksplit(m, n, a.kt);
+    const PrefillPlan plan = prefill_plan(m, n, a.kt);
+    a.ksplit = plan.ks;
     a.partial = nullptr;
+    bool wide = plan.wide;
     if (a.ksplit > 1) {
         const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
-        if (workspace && workspace_bytes >= need && aligned16(workspace))
+        if (workspace && workspace_bytes >= need && aligned16(workspace)) {
             a.partial = (float*)workspace;
-        else
+        } else {
             a.ksplit = 1;  // no room for the slices: whole k per tile (slower, same result class)
+            wide = false;
+        }
     }
     a.ktps = a.kt / a.ksplit;
-    if (a.ksplit == 1 && prefill_wide(m, n, a.kt)) {
+    if (wide) {
         static LdsOptIn lds_done;
         int rc = ensure_dynamic_lds((const void*)gemm_prefill_wide_kernel, kWLds, lds_done);
         if (rc != MV_OK) return rc;
@@ -622,10 +642,13 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
             const int v = atoi(e);
             a.mband = v <= 0 || v > a.mblocks ? a.mblocks : v;
         }
-        const long wgrid = 8L * a.nb_per_xcd * a.mblocks;
+        const long wgrid = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
         if (wgrid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(gemm_prefill_wide_kernel, dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
-        return check_launch();
+        rc = check_launch();
+        if (rc != MV_OK || a.ksplit == 1) return rc;
+        return launch_wgemm_finalize(a.partial, a.ksplit, m, n, flags, a.bias, a.residual, ld_res, y, ldy,
+                                     (hipStream_t)stream);
     }
     const long grid = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
     if (grid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;

@@ -72,7 +72,9 @@ def test_gemm_prefill_epilogues(mv):
 
 @pytest.mark.parametrize("m,n,k,mode", [(1000, 8208, 256, "plain"), (2300, 4096, 512, "residual"),
                                         (1025, 8192, 320, "bias"), (2048, 4096, 1024, "f32"),
-                                        (700, 22016, 256, "swiglu"), (4096, 2048, 4096, "plain")])
+                                        (700, 22016, 256, "swiglu"), (4096, 2048, 4096, "plain"),
+                                        # tiles for half the CUs and a long k: two k-slices of the wide form
+                                        (2000, 4096, 8192, "residual"), (1500, 4096, 8192, "bias")])
 def test_gemm_prefill_wide_form(mv, m, n, k, mode):
     """Shapes whose 256 x 256 tiles fill at least half the CUs take the wide form (both operands
     through LDS, eight waves on a tile): ragged last m- and n-blocks, every epilogue, k from the
@@ -81,6 +83,8 @@ def test_gemm_prefill_wide_form(mv, m, n, k, mode):
     from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
 
     assert nv.lib().mv_gemm_prefill_form(m, n, k) == 1, "this shape is meant to take the wide form"
+    if k >= 8192:
+        assert nv.lib().mv_gemm_prefill_workspace_bytes(m, n, k) == 2 * m * n * 4, "meant to be cut in two k-slices"
     x, w, g = _mk(m, n, k, seed=m + n + k, scale=0.03)
     bias = torch.randn(n, generator=g).to(torch.bfloat16) if mode == "bias" else None
     res = torch.randn(m, n, generator=g).to(torch.bfloat16) if mode == "residual" else None
