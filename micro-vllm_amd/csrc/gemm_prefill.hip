@@ -499,221 +499,6 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     store_wave_tile(a, acc, ntb + wn * 4, m0 + wm * 128, ks, r, q);
 }
 
-
-// ---- the same 256 x 256 tile on FOUR waves, one per SIMD, each owning 128 (n) x 128 (m) ---------
-// The eight-wave form reads 12 fragments per 32 MFMAs and wave: with two waves per SIMD that is 96 KiB
-// of LDS reads per k-tile and CU next to the 32 KiB the copies write - as many LDS cycles as the k-tile
-// has matrix cycles, so the two cannot hide behind each other.  A 128 x 128 wave tile needs 16
-// fragments per 64 MFMAs: 64 KiB of reads per k-tile, half the matrix time.  The price is one wave per
-// SIMD (256 accumulators a lane: nobody else to issue while this wave waits), so every memory
-// instruction is dealt out between the MFMAs by hand: per k-tile eight groups of eight MFMAs, in front of
-// each one copy instruction (x pieces first, then weight tiles) and two fragment reads for the next
-// k-tile.  Same LDS rings, same copy addressing, same tile walk and the same epilogue as the form above;
-// wave w copies weight tiles 4w..4w+3 and x m-tiles 4w..4w+3 of the block (an x stage in two halves, on
-// the odd k-tile and the even one after it, so every k-tile issues eight copies).
-constexpr int kBT = 8;   // n-tiles and m-tiles per wave
-
-// KIND: 0 = k-slice to the workspace, 1 = SwiGLU, 2 = fp32 out, 3 = bf16 out (+ bias, + residual)
-template <int KIND>
-__device__ __forceinline__ void store_big_tile(const PGemmArgs& a, const f32x4_t (&acc)[kBT][kPMT], int nt0,
-                                               int m0, int ks, int r, int q) {
-    const bool has_bias = a.bias != nullptr, has_res = a.residual != nullptr;
-#pragma unroll
-    for (int i = 0; i < kBT; ++i) {
-        const int nt = nt0 + i;
-        if (nt < a.nt) {   // uniform
-            const int n0 = nt * 16 + q * 4;
-            uint2 bv = make_uint2(0, 0);
-            if (KIND == 3 && has_bias) bv = *reinterpret_cast<const uint2*>(a.bias + n0);
-#pragma unroll
-            for (int t = 0; t < kPMT; ++t) {
-                const int m = m0 + t * 16 + r;
-                const f32x4_t c = acc[i][t];
-                if (KIND == 0) {
-                    if (m < a.m) *reinterpret_cast<f32x4_t*>(&a.partial[((int64_t)ks * a.m + m) * a.n + n0]) = c;
-                } else if (KIND == 1) {
-                    f32x4_t g;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) g[j] = __shfl_xor(c[j], 32, 64);
-                    if (q < 2 && m < a.m) {
-                        uint2 o;
-                        o.x = pack_bf16x2(silu_mul_rounded(g[0], c[0]), silu_mul_rounded(g[1], c[1]));
-                        o.y = pack_bf16x2(silu_mul_rounded(g[2], c[2]), silu_mul_rounded(g[3], c[3]));
-                        *reinterpret_cast<uint2*>(
-                            &reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + nt * 8 + q * 4]) = o;
-                    }
-                } else if (KIND == 2) {
-                    if (m < a.m)
-                        *reinterpret_cast<f32x4_t*>(&reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n0]) = c;
-                } else if (m < a.m) {
-                    float v[4] = {round_bf16(c[0]), round_bf16(c[1]), round_bf16(c[2]), round_bf16(c[3])};
-                    if (has_bias) {
-                        v[0] = round_bf16(v[0] + bf16_lo(bv.x)); v[1] = round_bf16(v[1] + bf16_hi(bv.x));
-                        v[2] = round_bf16(v[2] + bf16_lo(bv.y)); v[3] = round_bf16(v[3] + bf16_hi(bv.y));
-                    }
-                    if (has_res) {
-                        const uint2 rv = *reinterpret_cast<const uint2*>(a.residual + (int64_t)m * a.ld_res + n0);
-                        v[0] = round_bf16(v[0] + bf16_lo(rv.x)); v[1] = round_bf16(v[1] + bf16_hi(rv.x));
-                        v[2] = round_bf16(v[2] + bf16_lo(rv.y)); v[3] = round_bf16(v[3] + bf16_hi(rv.y));
-                    }
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(&reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + n0]) = o;
-                }
-            }
-        }
-    }
-}
-
-__global__ __launch_bounds__(256, 1) void gemm_prefill_big_kernel(PGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    unsigned char* const xring = lds;
-    unsigned char* const wring = lds + 3 * kWXSlot;
-
-    const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r = lane & 15, q = lane >> 4;
-    const int wn = wid & 1, wm = wid >> 1;
-
-    const int tiles = 8 * a.nb_per_xcd * a.mblocks;
-    const int ks = blockIdx.x / tiles, bid = blockIdx.x - ks * tiles;
-    const int kt0 = ks * a.ktps, nkt = a.ktps;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int per_band = a.mband * a.nb_per_xcd;
-    const int band = min(idx / per_band, (a.mblocks - 1) / a.mband);
-    const int rows = min(a.mband, a.mblocks - band * a.mband);
-    const int j0 = idx - band * per_band;
-    const int nbl = j0 / rows;
-    const int nb = xcd * a.nb_per_xcd + nbl;
-    const int mb = band * a.mband + j0 % rows;
-    if (nb >= a.nblocks || nbl >= a.nb_per_xcd) return;
-    const int m0 = mb * kWM;
-    const int ntb = nb * (kWN / 16);
-    const int nstage = nkt >> 1;
-
-    const unsigned char* wbase[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        wbase[j] = reinterpret_cast<const unsigned char*>(a.w + ((int64_t)min(ntb + 4 * wid + j, a.nt - 1) * a.kt + kt0) * 64);
-    const unsigned wlane = lane * 16;
-    const unsigned char* xbase[4];
-    unsigned xlane[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int mt = 4 * wid + (j >> 1);
-        const int first = min(m0 + mt * 16, a.m - 1);
-        const int row = (j & 1) * 8 + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const int grow = min(m0 + mt * 16 + row, a.m - 1);
-        if ((j & 1) == 0) xbase[j >> 1] = reinterpret_cast<const unsigned char*>(a.x + (int64_t)first * a.ldx + kt0 * 32);
-        xlane[j] = (unsigned)(((int64_t)(grow - first) * a.ldx + c * 8) * 2);
-    }
-    const unsigned x_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xring;
-    const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wring;
-    auto copy = [&](const unsigned char* base, unsigned lane_off, unsigned dst) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     : : "v"(lane_off), "s"(base), "s"(dst) : "memory");
-    };
-    auto copy_w1 = [&](int kt, int slot, int j) {
-        const int ktc = min(kt, nkt - 1);
-        copy(wbase[j] + (int64_t)ktc * 1024, wlane, w_lds + slot * kWWSlot + (4 * wid + j) * 1024);
-    };
-    auto copy_x1 = [&](int st, int slot, int j) {
-        const int sc = min(st, nstage - 1);
-        copy(xbase[j >> 1] + sc * 128, xlane[j], x_lds + slot * kWXSlot + (4 * wid + (j >> 1)) * 2048 + (j & 1) * 1024);
-    };
-    const int xoff0 = (wm * 8) * 2048 + r * 128 + (((0 + q) ^ ((r >> 1) & 7)) * 16);
-    const int xoff1 = (wm * 8) * 2048 + r * 128 + (((4 + q) ^ ((r >> 1) & 7)) * 16);
-    const int woff = (wn * 8) * 1024 + lane * 16;
-
-    f32x4_t acc[kBT][kPMT];
-#pragma unroll
-    for (int i = 0; i < kBT; ++i)
-#pragma unroll
-        for (int t = 0; t < kPMT; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int st = 0; st < 3; ++st)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) copy_x1(st, st, j);
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) copy_w1(kt, kt, j);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
-    bf16x8_t wA[kBT], xA[kPMT], wB[kBT], xB[kPMT];
-    {
-        const unsigned char* wp = wring + woff;
-        const unsigned char* xp = xring + xoff0;
-#pragma unroll
-        for (int i = 0; i < kBT; ++i) wA[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + i * 1024));
-#pragma unroll
-        for (int t = 0; t < kPMT; ++t) xA[t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp + t * 2048));
-    }
-    __syncthreads();
-
-    auto ktile = [&](bf16x8_t(&wc)[kBT], bf16x8_t(&xc)[kPMT], bf16x8_t(&wnx)[kBT], bf16x8_t(&xnx)[kPMT], int kt,
-                     bool odd) {
-        const int ktn = min(kt + 1, nkt - 1);
-        const unsigned char* wp = wring + (ktn & 3) * kWWSlot + woff;
-        const unsigned char* xp = xring + ((ktn >> 1) % 3) * kWXSlot + ((ktn & 1) ? xoff1 : xoff0);
-        // x stage being copied: the first half goes out on the odd k-tile that frees its slot, the
-        // second half on the even k-tile after it
-        const int xst = odd ? (kt >> 1) + 3 : (kt >> 1) + 2;
-        const int xslot = odd ? (kt >> 1) % 3 : ((kt >> 1) + 2) % 3;
-#pragma unroll
-        for (int t = 0; t < kPMT; ++t) {
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef MV_BIG_NO_COPY      // (MV_BIG_NO_*: timing experiments, wrong results)
-            if (t < 4) copy_x1(xst, xslot, (odd ? 0 : 4) + t);
-            else copy_w1(kt + 4, kt & 3, t - 4);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef MV_BIG_NO_READ
-            wnx[t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + t * 1024));
-            xnx[t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp + t * 2048));
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-            // accumulators pinned to the accumulation registers, fragments to the vector registers:
-            // left to choose, the allocator spreads both over both files and moves some two hundred
-            // registers around at every turn of the loop
-#pragma unroll
-            for (int i = 0; i < kBT; ++i)
-#ifdef MV_BIG_NO_MFMA
-                asm volatile("" : "+a"(acc[i][t]) : "v"(wc[i]), "v"(xc[t]));
-#else
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][t]) : "v"(wc[i]), "v"(xc[t]));
-#endif
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // the pieces of k-tile kt + 2 (and of its x stage) were requested during k-tile kt - 2 at the
-        // latest: sixteen younger copies may be outstanding; the fragment reads of kt + 1 are complete
-        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-#ifndef MV_BIG_NO_BARRIER
-        __syncthreads();
-#endif
-    };
-    for (int kt = 0; kt < nkt; kt += 2) {
-        ktile(wA, xA, wB, xB, kt, false);
-        ktile(wB, xB, wA, xA, kt + 1, true);
-    }
-    // (the matrix instructions above are invisible to the compiler's hazard bookkeeping: the last
-    // results are given their passes before anything reads them)
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-
-    const int nt0 = ntb + wn * kBT, mw = m0 + wm * 128;
-    if (nt0 >= a.nt) return;
-    // the epilogue of store_wave_tile, one copy per output kind: 64 accumulator tiles a lane only
-    // stay in registers when every index into them is a constant, and the four kinds in one body are
-    // more code than the compiler unrolls
-    if (a.partial) store_big_tile<0>(a, acc, nt0, mw, ks, r, q);
-    else if (a.flags & MV_GEMM_SWIGLU) store_big_tile<1>(a, acc, nt0, mw, ks, r, q);
-    else if (a.flags & MV_GEMM_OUT_F32) store_big_tile<2>(a, acc, nt0, mw, ks, r, q);
-    else store_big_tile<3>(a, acc, nt0, mw, ks, r, q);
-}
-
 }  // namespace mv
 
 #ifdef MV_GEMM_STAMP
@@ -859,16 +644,6 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
         }
         const long wgrid = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
         if (wgrid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
-        static const bool four_waves = [] {
-            const char* e = getenv("MVLLM_PREFILL_FOUR_WAVES");
-            return e && *e && atoi(e) != 0;
-        }();
-        if (four_waves) {
-            static LdsOptIn lds_big;
-            rc = ensure_dynamic_lds((const void*)gemm_prefill_big_kernel, kWLds, lds_big);
-            if (rc != MV_OK) return rc;
-            hipLaunchKernelGGL(gemm_prefill_big_kernel, dim3((unsigned)wgrid), dim3(256), kWLds, (hipStream_t)stream, a);
-        } else
         hipLaunchKernelGGL(gemm_prefill_wide_kernel, dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
         rc = check_launch();
         if (rc != MV_OK || a.ksplit == 1) return rc;
