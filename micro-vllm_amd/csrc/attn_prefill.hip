@@ -26,6 +26,21 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
 constexpr float kPfNegBig = -1.0e30f;
+
+// Maximum over lanes l, l ^ 16, l ^ 32, l ^ 48 (the four lanes that hold one query's scores), in the
+// vector unit: v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of
+// the other, v_permlane32_swap the upper half of one with the lower half of the other - given the
+// same value twice, the two results hold a lane's own row (half) and its partner's.  The shuffle
+// intrinsic goes through the LDS crossbar instead (ds_bpermute_b32 and a wait for every LDS operation
+// in flight), twice per query tile and key tile: 213 -> 198 us per layer at 4096 tokens.
+__device__ __forceinline__ float max_over_lane_quarters(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    const float m = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const unsigned w = __float_as_uint(m);
+    const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
 constexpr int kPfWideFrom = 2048;   // chunk length from which 8-wave workgroups are taken
 // waves per workgroup of the attention kernel forced by MVLLM_PREFILL_ATTN_WAVES (4 or 8; read once)
 static const int g_pf_waves = [] {
@@ -331,8 +346,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void paged_attn_prefill_k
 #pragma unroll
             for (int x = 0; x < 4; ++x) m4[x] = fmaxf(fmaxf(s[4 * x], s[4 * x + 1]), fmaxf(s[4 * x + 2], s[4 * x + 3]));
             float mloc = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3])) * a.scale_log2;
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 16, 64));
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+            mloc = max_over_lane_quarters(mloc);
             // the running maximum moves in few tiles once the first are in: the rescale of the 32
             // output accumulators is skipped while it stands for every row of the wave (a factor
             // of exactly 1 otherwise: same result)
