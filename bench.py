@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prefill", action="store_true", help="skip the prefill leg of the report")
     ap.add_argument("--no-bs32", action="store_true", help="skip the batch-32 legs of the report")
+    ap.add_argument("--no-engine", action="store_true",
+                    help="skip the InferenceEngine leg of the report (32 requests, prefill and decode mixed)")
     ap.add_argument("--chain", action="store_true",
                     help="A/B switch: one launch per block for the projections of a small batch (grid barriers)")
     ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
@@ -377,6 +379,70 @@ def shape_table(runner, bs, layers):
     return rows
 
 
+class _CharTokenizer:
+    """One token per character, no end-of-sequence token among them (the engine leg needs a tokenizer
+    object; there is no vocabulary file offline)."""
+    eos_token_id = 1
+
+    def __init__(self, vocab):
+        self.vocab = vocab
+
+    def encode(self, prompt, add_special_tokens=True):
+        return [5 + (ord(c) * 7919) % (self.vocab - 5) for c in prompt]
+
+    def decode(self, ids, skip_special_tokens=True):
+        return " ".join(str(i) for i in ids)
+
+
+def engine_leg(cfg, model, requests=32, prompt_tokens=512, new_tokens=128):
+    """The continuous-batching configuration as the reference runs it: `requests` prompts through
+    InferenceEngine.generate - scheduler, bucketed prefill batches under max_prefill_tokens, padded
+    decode batches replaying captured graphs, greedy pick on the device, update_sequences on the host.
+    Generated tokens over the wall time of the whole job (second of two repetitions)."""
+    from micro_vllm_amd.core.engine import InferenceEngine
+
+    blocks = requests * ((prompt_tokens + new_tokens + 255) // 256 + 1) + 4
+    eng = InferenceEngine(model=model, tokenizer=_CharTokenizer(cfg.vocab_size), max_batch_size=requests,
+                          max_prefill_tokens=max(2048, prompt_tokens), n_blocks=blocks,
+                          max_tokens=prompt_tokens + new_tokens + 256,
+                          graph_batch_sizes=[b for b in (1, 2, 4, 8, 16, 32) if b <= requests] or [requests],
+                          prefill_timeout=0.0)
+    prompts = ["".join(chr(33 + (i * 31 + j * 7) % 90) for j in range(prompt_tokens)) for i in range(requests)]
+    steps = {"prefill": [0, 0.0], "decode": [0, 0.0]}
+    inner = eng.step
+
+    def timed_step(ctx):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        r = inner(ctx)
+        torch.cuda.synchronize()
+        k = steps[ctx.batch_type if ctx.batch_type in steps else "decode"]
+        k[0] += 1
+        k[1] += time.perf_counter() - t
+        return r
+
+    eng.step = timed_step
+    for _ in range(2):
+        for k in steps.values():
+            k[0], k[1] = 0, 0.0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = eng.generate(prompts, max_tokens=new_tokens, temperature=0.0, top_p=0.9)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    ntok = sum(len(v.split()) for v in out.values()) - requests * prompt_tokens
+    assert len(out) == requests and ntok > 0
+    return {"metric": "generated tokens/sec through InferenceEngine.generate (scheduler + prefill batches + "
+                      "padded decode batches, whole job)",
+            "value": round(ntok / dt, 1), "unit": "tokens/s", "requests": requests,
+            "prompt_tokens": prompt_tokens, "new_tokens": new_tokens, "max_batch_size": requests,
+            "job_ms": round(dt * 1e3, 1), "generated": ntok,
+            "prefill_steps": steps["prefill"][0], "prefill_ms": round(steps["prefill"][1] * 1e3, 1),
+            "decode_steps": steps["decode"][0],
+            "decode_ms_per_step": round(steps["decode"][1] / max(1, steps["decode"][0]) * 1e3, 3),
+            "sampling": "greedy"}
+
+
 def cpu_baseline(args, cfg, runner, dev):
     """The CPU restatement of the reference's decode path (oracle/ref_model.py) on the host cores:
     2 transformer layers + final norm + LM head of the same random model at the same context,
@@ -623,6 +689,12 @@ def main():
             except Exception as e:
                 log(f"[bench] prefill leg failed: {e!r}")
                 out["prefill"] = None
+        if world == 1 and bs == 1 and not args.no_engine and args.model == "llama3-8b":
+            try:
+                out["engine_bs32"] = engine_leg(cfg, runner.model)
+            except Exception as e:
+                log(f"[bench] engine leg failed: {e!r}")
+                out["engine_bs32"] = None
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, cfg, runner, dev)

@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-SHORT="--steps 3 --warmup 1 --tail-steps 0 --no-cpu-baseline --no-prefill --no-bs32"
+SHORT="--steps 3 --warmup 1 --tail-steps 0 --no-cpu-baseline --no-prefill --no-bs32 --no-engine"
 run() { echo "== $*"; "$@" || { echo "FAILED: $*"; exit 1; }; }
 run timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o "$TAG" -- python3 "$ROOT/bench.py" --steps 50 --warmup 10 --no-cpu-baseline > "$OUT/trace_bench.json" 2> "$OUT/trace_bench.err"
 for BS in 1 32; do
