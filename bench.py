@@ -529,7 +529,24 @@ def main():
     if not args.no_graph:
         if args.one_split_rule:
             runner.uneven_ratio = float("inf")
-        runner.capture(mgr, batch_sizes=[bs])
+        captured = 1
+        try:
+            runner.capture(mgr, batch_sizes=[bs])
+        except Exception as e:
+            if not peers:
+                raise
+            log(f"[bench] rank {rank}: capture failed ({e!r})")
+            captured = 0
+        if peers:
+            # every rank replays a graph or none does: a rank that decodes eagerly beside ranks that
+            # replay would still issue the same reductions, but the timing would be of a mixture
+            t = torch.tensor([captured], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            if int(t.item()) == 0:
+                log(f"[bench] rank {rank}: a rank could not capture its step; every rank decodes eagerly")
+                runner._graphs.clear()
+                runner._graphs_uneven.clear()
+                runner._is_graph_ready = True
     torch.cuda.synchronize()
     log(f"[bench] rank {rank}/{world}: {cfg.name} x{layers} layers built + captured in {time.time()-t_build:.1f}s")
 
