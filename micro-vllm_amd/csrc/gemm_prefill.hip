@@ -540,6 +540,8 @@ static int prefill_ksplit(int m, int n, int kt) {
 // down projection at 1536-2048 tokens: 96-128 tiles of 224 stages; one workgroup per CU then walks
 // half the stages, and only a long k pays for the 8 bytes per output the slices write and read back
 // plus the reduction launch: 2048 tokens 268 -> 216 us; at 2304 tokens, 144 tiles, 344 against 300).
+// Since the slab reduction reads 16 bytes a lane (15 us for 67 MB of slabs where it took 43) the same
+// holds from k = 4096: the O projection at 1536 tokens 85 -> 67 us, at 2048 tokens 93 -> 89.
 // MVLLM_PREFILL_WIDE = 0 / 1 forces the choice of form (read once).
 struct PrefillPlan {
     bool wide;
@@ -554,7 +556,7 @@ static PrefillPlan prefill_plan(int m, int n, int kt) {
     if (kt < 8 || forced == 0) return {false, narrow_ks};
     const long tiles = (long)((m + kWM - 1) / kWM) * ((n + kWN - 1) / kWN);
     const int cus = num_cus();
-    if (forced < 0 && kt >= 256 && kt % 4 == 0 && 8 * tiles >= 3L * cus && 2 * tiles <= cus) return {true, 2};
+    if (forced < 0 && kt >= 128 && kt % 4 == 0 && 8 * tiles >= 3L * cus && 2 * tiles <= cus) return {true, 2};
     if (narrow_ks == 1 && (forced == 1 || 2 * tiles >= cus)) return {true, 1};
     return {false, narrow_ks};
 }
