@@ -258,7 +258,7 @@ int mv_paged_attn_tune(int key, int value);
  * (kv_stride_b), caches: [num_pages, page, Hkv, D] contiguous, cache_seqlens: int32 [bs],
  * block_table: int32 [bs, bt_stride] (-1 = unallocated, never dereferenced for
  * indices <= p / page unless the caller broke the contract, in which case the key is
- * skipped), out: [bs,Hq,D] contiguous.  D in {64,128}; Hq/Hkv in {1,2,4,8}.
+ * skipped), out: [bs,Hq,D] contiguous.  D in {64,128}; Hq/Hkv from 1 to 8.
  * workspace: see mv_paged_attn_decode_workspace_bytes (zero-filled once by the caller; calls
  * that may overlap on one GPU need a workspace each).
  * Replaces the flash_attn_with_kvcache call at core/layer/model_graph.py:161-168
@@ -311,7 +311,8 @@ int mv_rope_store_prefill(void* qkv, int64_t row_stride, const void* rot_cos, co
  * keys 0 .. cache_seqlens[b] + i (bottom-right aligned mask), q head h reads kv head h / (Hq/Hkv).
  * q rows: [bs*seq][q_stride] with heads contiguous; out rows likewise.  fp32 scores and softmax,
  * P rounded to bf16 as the matrix-core operand, fp32 accumulation, bf16 output.
- * D in {64,128}; Hq/Hkv in {1,2,4,8}; page a power of two >= 64.
+ * D in {64,128}; Hq/Hkv from 1 to 8 (3, 5, 6 and 7 take the row stack of the next power of two: the rows of
+ * the heads that do not exist are computed and dropped); page a power of two >= 64.
  * With the store above this replaces flash_attn_with_kvcache(q, k_cache, v_cache, k=, v=,
  * cache_seqlens=, block_table=, causal=True) at core/layer/model_prefill.py:49-52. */
 int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, const void* v_cache,

@@ -95,11 +95,11 @@ class InferenceEngine:
         self.head_size = getattr(cfg, "head_dim", cfg.hidden_size // heads)
         assert heads % world == 0 and kv_heads % world == 0
         # what the attention kernels are built for - checked before any weight moves to the device
-        if self.head_size not in (64, 128) or heads % kv_heads or heads // kv_heads not in (1, 2, 4, 8):
+        if self.head_size not in (64, 128) or heads % kv_heads or not 1 <= heads // kv_heads <= 8:
             raise ValueError(
                 f"unsupported attention shape: head size {self.head_size} (supported: 64, 128), "
                 f"{heads} query heads on {kv_heads} kv heads = {heads / kv_heads:g} per kv head "
-                f"(supported: 1, 2, 4, 8)")
+                f"(supported: 1 to 8)")
         self.num_heads, self.kv_num_heads = heads // world, kv_heads // world
         self.intermediate_size = cfg.intermediate_size // world
 

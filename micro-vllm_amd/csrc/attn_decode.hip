@@ -193,14 +193,17 @@ __device__ __forceinline__ void finish_states(const AttnArgs& a, float* lds, int
     // (head, 4 consecutive d) item and every PARTS-th split of it; its 16-byte loads and the
     // lse loads are all issued before anything waits, so the merge costs about one memory
     // round trip.  Partial sums meet in LDS in a fixed order (results are deterministic).
+    // (With 3, 5, 6 or 7 query heads per kv head the items do not divide the threads: the threads
+    // past the last whole part sit the merge out.)
     constexpr int ITEMS = G * D / 4;
     constexpr int PARTS = kAT / ITEMS;
-    static_assert(ITEMS * PARTS == kAT, "one (item, part) per thread");
+    static_assert(PARTS >= 1, "at least one thread per (head, 4 consecutive d)");
     constexpr int kMU = PARTS >= 8 ? 4 : 16;  // loads in flight per thread
     const int ns = a.nsplit;
     float* wts = lds;                 // [G][nsplit] weights 2^(lse - max) / sum
     float* psum = lds + G * 128;      // [PARTS][ITEMS][4] (nsplit <= 128)
     const int item = threadIdx.x % ITEMS, part = threadIdx.x / ITEMS;
+    const bool active = part < PARTS;
     const int mg = item / (D / 4), md4 = (item - mg * (D / 4)) * 4;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
         a.part_o + ((int64_t)b * a.hq + kvh * G) * ns * D, 0, G * ns * D * 4, 0x00020000);
@@ -225,7 +228,7 @@ __device__ __forceinline__ void finish_states(const AttnArgs& a, float* lds, int
                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
     u32x4_t v0[kMU];
-    load_batch(v0, part);
+    if (active) load_batch(v0, part);
     for (int g = wg0; g < G; g += kAW) {
         if (g != wg0) {  // only when there are more heads than waves
             const int64_t pi = ((int64_t)b * a.hq + kvh * G + g) * ns;
@@ -249,7 +252,7 @@ __device__ __forceinline__ void finish_states(const AttnArgs& a, float* lds, int
     MV_ASTAMP(9);
     __syncthreads();
     MV_ASTAMP(10);
-    {
+    if (active) {
         const float* w = wts + mg * ns;
         f32x4_t acc_o = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         auto consume = [&](const u32x4_t(&v)[kMU], int s0) {
@@ -945,7 +948,11 @@ static int dispatch_g(const AttnArgs& a, int g, hipStream_t s) {
     switch (g) {
         case 1: return launch_decode<D, 1>(a, s);
         case 2: return launch_decode<D, 2>(a, s);
+        case 3: return launch_decode<D, 3>(a, s);
         case 4: return launch_decode<D, 4>(a, s);
+        case 5: return launch_decode<D, 5>(a, s);
+        case 6: return launch_decode<D, 6>(a, s);
+        case 7: return launch_decode<D, 7>(a, s);
         case 8: return launch_decode<D, 8>(a, s);
         default: return MV_ERR_UNSUPPORTED;
     }

@@ -52,9 +52,15 @@ static const int g_pf_waves = [] {
 // 256-row (8-wave) workgroups for long chunks (measured: 4096 tokens 202 against 220-229 us per layer
 // of the 8B shape, 8 x 1024 tokens 126 against 121) that fill their last round of one workgroup per
 // CU to nine tenths (3072 tokens: 384 workgroups on 256 CUs, 133 against 121 us)
+static int pf_group_slots(int g) {   // query heads per kv head, rounded up to a power of two
+    int gp = 1;
+    while (gp < g) gp <<= 1;
+    return gp;
+}
+
 static bool pf_eight_waves(int bs, int seq, int hkv, int g) {
     if (g_pf_waves) return g_pf_waves == 8;
-    const int qt8 = 256 / g;
+    const int qt8 = 256 / pf_group_slots(g);
     const int64_t grid8 = (int64_t)((seq + qt8 - 1) / qt8) * hkv * bs;
     const int64_t rounds8 = (grid8 + num_cus() - 1) / num_cus();
     return seq >= kPfWideFrom && grid8 * 10 >= rounds8 * num_cus() * 9;
@@ -169,7 +175,7 @@ struct PfArgs {
     uint16_t* out;          // [B*S][out_stride]
     int64_t out_stride;
     int B, S, hq, hkv, g;
-    int qt, qt_shift;       // query positions per workgroup = (128 or 256) / g
+    int qt, qt_shift;       // query positions per workgroup = (128 or 256) / (g rounded up to a power of two)
     int nqb;
     int page_shift, num_pages, page;
     float scale_log2;
@@ -207,14 +213,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void paged_attn_prefill_k
     const int32_t* bt = a.block_table + (int64_t)b * a.bt_stride;
 
     // this lane's query rows (C-layout column r of each of the wave's two tiles)
+    // (3, 5, 6 or 7 query heads per kv head: the stack has room for the next power of two; the rows
+    // of the heads that do not exist repeat the last real head and are never stored)
     int limit[2], qi[2], head[2];
     bf16x8_t qf[2][KS];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int row = wid * 32 + mt * 16 + r;
         const int gi = row >> a.qt_shift, i = i0 + (row & (a.qt - 1));
-        head[mt] = kvh * a.g + gi;
-        qi[mt] = i;
+        head[mt] = kvh * a.g + min(gi, a.g - 1);
+        qi[mt] = gi < a.g ? i : a.S;   // a position past the chunk: not stored
         const int ic = min(i, a.S - 1);
         limit[mt] = p0 + ic;
         const uint16_t* qp = a.q + ((int64_t)b * a.S + ic) * a.q_stride + (int64_t)head[mt] * D + q * 8;
@@ -504,7 +512,7 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
     if (d != 64 && d != 128) return MV_ERR_UNSUPPORTED;
     if (hq % hkv) return MV_ERR_UNSUPPORTED;
     const int g = hq / hkv;
-    if (g != 1 && g != 2 && g != 4 && g != 8) return MV_ERR_UNSUPPORTED;
+    if (g < 1 || g > 8) return MV_ERR_UNSUPPORTED;
     if ((page & (page - 1)) || page < 64) return MV_ERR_UNSUPPORTED;  // a 64-key tile sits in one page
     if (!aligned16(q) || !aligned16(k_cache) || !aligned16(v_cache) || !aligned16(out) ||
         (q_stride % 8) != 0 || (out_stride % 4) != 0 || q_stride < (int64_t)hq * d ||
@@ -525,9 +533,10 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
     a.hq = hq;
     a.hkv = hkv;
     a.g = g;
-    const int qt8 = 256 / g;
+    const int gp = pf_group_slots(g);
+    const int qt8 = 256 / gp;
     const bool wide = pf_eight_waves(bs, seq, hkv, g);
-    a.qt = wide ? qt8 : 128 / g;
+    a.qt = wide ? qt8 : 128 / gp;
     const bool eight = a.qt == qt8;
     a.qt_shift = __builtin_ctz((unsigned)a.qt);
     a.nqb = (seq + a.qt - 1) / a.qt;

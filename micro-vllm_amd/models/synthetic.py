@@ -68,6 +68,9 @@ SHAPES = {
     "tiny-gqa": SyntheticConfig("tiny-gqa", 512, 256, 2, 8, 2, 64, 512, 1e-6, 2048),
     "tiny-mha": SyntheticConfig("tiny-mha", 512, 256, 2, 4, 4, 64, 384, 1e-6, 2048),
     "tiny-d128": SyntheticConfig("tiny-d128", 1024, 512, 2, 8, 2, 128, 1024, 1e-5, 2048),
+    # query heads per kv head that are no power of two (the ratios of the Qwen2 family: 7, 6, 5)
+    "tiny-gqa7": SyntheticConfig("tiny-gqa7", 512, 448, 2, 7, 1, 64, 512, 1e-6, 2048),
+    "tiny-gqa6-d128": SyntheticConfig("tiny-gqa6-d128", 512, 768, 2, 6, 1, 128, 512, 1e-6, 2048),
     # eight kv heads: divisible by every tensor-parallel degree up to 8
     "tiny-kv8": SyntheticConfig("tiny-kv8", 512, 256, 2, 16, 8, 64, 512, 1e-6, 2048),
 }

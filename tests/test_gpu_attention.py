@@ -88,7 +88,9 @@ def run_both(case, num_splits=0):
 
 
 @pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 2), (128, 4, 4), (128, 8, 1), (128, 4, 2),
-                                      (64, 8, 2), (64, 8, 1), (64, 4, 4), (64, 2, 1)])
+                                      (64, 8, 2), (64, 8, 1), (64, 4, 4), (64, 2, 1),
+                                      # 7, 6, 5 and 3 query heads per kv head (Qwen2-style ratios)
+                                      (128, 14, 2), (128, 12, 2), (128, 5, 1), (64, 6, 2), (64, 7, 1)])
 @pytest.mark.parametrize("splits", [1, 3, 0])
 def test_decode_attention_vs_oracle(mv, D, Hq, Hkv, splits):
     ctxs = [0, 1, 15, 16, 17, 255, 256, 257, 700]

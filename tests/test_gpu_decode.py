@@ -79,7 +79,8 @@ def FREE_RUN_ATOL(want):
 
 
 CASES = [("tiny-gqa", False, True), ("tiny-gqa", False, False), ("tiny-mha", True, True),
-         ("tiny-mha", True, False), ("tiny-d128", False, True)]
+         ("tiny-mha", True, False), ("tiny-d128", False, True),
+         ("tiny-gqa7", True, True), ("tiny-gqa6-d128", False, True), ("tiny-gqa6-d128", False, False)]
 
 
 @pytest.mark.parametrize("shape,bias,fused", CASES)

@@ -76,7 +76,9 @@ def test_rope_store_fills_the_pages_bit_exactly(mv, D, Hq, Hkv):
     assert torch.equal(kcd.cpu(), want_k) and torch.equal(vcd.cpu(), want_v)
 
 
-@pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 2), (128, 4, 4), (64, 8, 1), (64, 4, 2)])
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 8, 2), (128, 4, 4), (64, 8, 1), (64, 4, 2),
+                                      # 7, 6, 5 and 3 query heads per kv head: padded to 8 / 4 in the row stack
+                                      (128, 14, 2), (64, 6, 1), (128, 5, 1), (64, 6, 2)])
 @pytest.mark.parametrize("S,starts", [(1, [0, 5]), (17, [0, 300]), (130, [0, 0]), (300, [256, 1])])
 def test_prefill_attention_vs_oracle(mv, D, Hq, Hkv, S, starts):
     """Kernel output against the exact-softmax oracle within 1e-3 + one output ulp + the bound of
@@ -145,7 +147,8 @@ def _build(mv, shape, qkv_bias=False, n_blocks=24, max_bs=4, p_bf16=False):
     return cfg, decode, prefill, mgr, ref, ref_cache
 
 
-@pytest.mark.parametrize("shape,bias,S", [("tiny-gqa", False, 40), ("tiny-mha", True, 150), ("tiny-d128", False, 290)])
+@pytest.mark.parametrize("shape,bias,S", [("tiny-gqa", False, 40), ("tiny-mha", True, 150), ("tiny-d128", False, 290),
+                                          ("tiny-gqa7", True, 70), ("tiny-gqa6-d128", False, 130)])
 def test_prefill_runner_per_layer_and_end_to_end(mv, shape, bias, S):
     # the matrix-core kernel rounds P to bf16 like the package the reference calls: compare with
     # the oracle form that does the same
