@@ -210,7 +210,9 @@ def projection_timing(runner, bs, layers, reps=20):
                 wgemm_postnorm(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs], b.ln_1.weight, b.ln_1.eps,
                                normed, residual=resid, var_from_rounded=True, workspace=ws)
             n += 4
-        if bs <= 4:
+        if getattr(runner, "_gatherer", None) is not None:   # several ranks, head cut by vocabulary rows
+            wgemm(normed, runner._lm_head_shard, runner._logits_local[:bs], workspace=ws)
+        elif bs <= 4:
             wgemm_norm(h, tr.ln_f.weight, tr.ln_f.eps, runner._lm_head, runner._logits[:bs], workspace=ws)
         else:
             wgemm(normed, runner._lm_head, runner._logits[:bs], workspace=ws)
@@ -632,10 +634,11 @@ def main():
     tok_s = bs * args.steps / dt
 
     # ---- algorithmic bytes of one step on one GPU ---------------------------------------
-    full_cfg_bytes = cfg.weight_bytes(world)
+    head_sharded = getattr(runner, "_gatherer", None) is not None   # LM head cut by vocabulary rows
+    full_cfg_bytes = cfg.weight_bytes(world, head_sharded)
     if layers != cfg.num_hidden_layers:  # debug slices: count what was built
         import dataclasses
-        full_cfg_bytes = dataclasses.replace(cfg, num_hidden_layers=layers).weight_bytes(world)
+        full_cfg_bytes = dataclasses.replace(cfg, num_hidden_layers=layers).weight_bytes(world, head_sharded)
     kv_tok = cfg.kv_bytes_per_token(world) * layers // cfg.num_hidden_layers
     mean_keys = sum(ctxs) / bs + (pos0 + pos0 + args.steps - 1) / 2.0 + 1.0
     kv_bytes = bs * (mean_keys + 1.0) * kv_tok
@@ -664,6 +667,8 @@ def main():
             "layers": layers,
             "parallelism": (f"rank 0 of tp{world} alone on one GPU: no peers, every reduction sums one partial"
                             if args.as_rank_of else f"tp{world}"),
+            "lm_head": ("cut by vocabulary rows over the ranks, logits all-gathered" if head_sharded
+                        else "whole on every rank"),
             "graph": bs in runner._graphs,   # False when capture was skipped or fell back to eager
             # the step replayed the graph with the finer attention split (rows of uneven length)
             "uneven_split_graph": bs in runner._graphs_uneven and runner._rows_uneven(mgr, bs),

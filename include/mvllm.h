@@ -395,6 +395,20 @@ int mv_allreduce_destroy(void* comm);
 int mv_allreduce_step(void* comm, const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
                       int n, mv_stream_t stream);
 
+/* All-gather of [rows, n_local] bf16 slices into [rows, world * n_local] rows on every rank, through
+ * a communicator of its own (same handle / connect / status / set_timeout / destroy calls as above):
+ *   mv_allgather_init   exchange buffer for up to max_rows rows of world x n_local columns
+ *                       (n_local a multiple of 8);
+ *   mv_allgather_rows   rank r's `in` lands at columns [r * n_local, (r + 1) * n_local) of `out` on every
+ *                       rank; takes the stream, never synchronises, legal under stream capture.
+ * No counterpart in the reference, which keeps the LM head whole on every rank (core/layer/
+ * model_graph.py:222-223): with the head cut by vocabulary rows each rank multiplies 1/world of it and
+ * the ranks exchange their logits instead (at 8 ranks of the 8B shape 1/8 of the largest single
+ * projection of a decode step). */
+int mv_allgather_init(int rank, int world, int max_rows, int n_local, void** comm_out);
+int mv_allgather_rows(void* comm, const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
+                      int n_local, mv_stream_t stream);
+
 /* The all-reduce together with what a decoder block does next (core/layer/model_graph.py:210-213 and
  * :219 + :143 of the following block), one launch:
  *   t = bf16(sum over ranks of partial);  s = t + residual;  y = bf16(s);

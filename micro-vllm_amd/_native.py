@@ -92,6 +92,8 @@ PROTOTYPES = {
     "mv_allreduce_set_timeout_ms": (_I, [_P, ctypes.c_double]),
     "mv_allreduce_destroy": (_I, [_P]),
     "mv_allreduce_step": (_I, [_P, _P, _L, _P, _L, _I, _I, _P]),
+    "mv_allgather_init": (_I, [_I, _I, _I, _I, ctypes.POINTER(c_void_p)]),
+    "mv_allgather_rows": (_I, [_P, _P, _L, _P, _L, _I, _I, _P]),
     "mv_allreduce_addnorm": (_I, [_P, _P, _L, _P, _I, _P, _L, _P, _L, _P, _F, _P, _L, _I, _I, _I, _P]),
     "mv_graph_begin_capture": (_I, [_P]),
     "mv_graph_end_capture": (_I, [_P, ctypes.POINTER(c_void_p)]),

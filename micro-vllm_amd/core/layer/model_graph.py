@@ -124,8 +124,15 @@ class ModelGraphRunner:
                                         rope_base=float(getattr(model.config, "rope_theta", 10000.0)))
         self.prepare_weights()
         self._alloc_bufs()
+        self._gatherer = None
         if self.world_size > 1 and self._reducer is None:
             self._reducer = pc.tensor_parallel_reducer(min(max_batch_size, 64), hidden_dim)
+            if self._lm_head_shard is not None and max_batch_size <= 64:
+                # every rank asks (the set-up is a vote among the ranks), whatever it will answer
+                self._gatherer = pc.tensor_parallel_gatherer(max_batch_size, self.vocab_size // self.world_size)
+        if self._gatherer is not None:
+            self._logits_local = torch.empty(max_batch_size, self.vocab_size // self.world_size,
+                                             dtype=dtype, device=device)
         self._graphs: Dict[int, HipGraph] = {}
         # second graph per batch size, captured with a finer attention split: replayed when the
         # rows of a step differ much in length (the longest row alone then sets the pace of an
@@ -172,12 +179,25 @@ class ModelGraphRunner:
         tr.ln_f.weight = tr.ln_f.weight.to(dev)
         # embedding, final norm and LM head are replicated on every rank (model_graph.py:196,222-223)
         shared = getattr(self.model, "_mv_lm_head_tiles", None)
+        shards = getattr(self.model, "_mv_lm_head_shards", None)
+        if shards is None:
+            shards = self.model._mv_lm_head_shards = {}
+        # ... and, with several ranks, this rank's slice of the head by vocabulary rows next to it: the
+        # decode step multiplies the slice and collects the ranks' logits when a gatherer is available
+        # (kernel/allreduce.py::IpcAllGather), the whole head otherwise - decided after the weights
+        v_local = self.vocab_size // self.world_size
+        key = (self.rank, self.world_size)
+        if (self.world_size > 1 and key not in shards and self.vocab_size % (16 * self.world_size) == 0
+                and getattr(self.model.lm_head, "weight", None) is not None):
+            w = self.model.lm_head.weight[self.rank * v_local:(self.rank + 1) * v_local]
+            shards[key] = StreamedWeight.from_linear(w.to(dev).contiguous())
         if shared is None:
             shared = StreamedWeight.from_linear(self.model.lm_head.weight.to(dev))
             self.model._mv_lm_head_tiles = shared
             if self.release_source_weights:
                 self.model.lm_head.weight = None
         self._lm_head = shared
+        self._lm_head_shard = shards.get(key)
         torch.cuda.synchronize()
         logger.info("weights relaid out (rank %d)", self.rank)
 
@@ -543,6 +563,10 @@ class ModelGraphRunner:
             nxt = blocks[layer_idx + 1].ln_1 if layer_idx + 1 < self.num_layers else tr.ln_f
             row_parallel(self._swiglu_out[:bs], block.mlp._d, self._residual[:bs], nxt, self._mlp_out[:bs], True)
             h = self._mlp_out[:bs]
+        if self._gatherer is not None:
+            # the head cut by vocabulary rows: 1 / world of its bytes per rank, then one exchange
+            wgemm(normed, self._lm_head_shard, self._logits_local[:bs], workspace=ws)
+            return self._gatherer.gather(self._logits_local[:bs], self._logits[:bs])
         return wgemm(normed, self._lm_head, self._logits[:bs], workspace=ws)
 
     def greedy_ids(self, logits: torch.Tensor):

@@ -11,6 +11,7 @@ import torch.distributed as dist
 class _State:
     group = None
     reducer = None
+    gatherer = None
 
 
 _st = _State()
@@ -89,21 +90,29 @@ def tensor_parallel_reducer(max_rows: int, max_n: int):
         return red
     if red is not None:
         red.close()
-    group = get_group() or dist.group.WORLD
-    comm, ok = None, 0
     want_ipc = (os.environ.get("MVLLM_ALLREDUCE", "ipc") != "dist" and torch.cuda.is_available()
                 and world <= 8 and max_rows <= MAX_ROWS and max_n <= MAX_N and max_n % 8 == 0)
+    comm = _agree_on_ipc_comm(lambda: IpcAllReduce(get_rank(), world, max_rows, max_n), want_ipc,
+                              "one-shot all-reduce")
+    _st.reducer = comm if comm is not None else DistAllReduce(all_reduce)
+    return _st.reducer
 
-    # Every rank takes part in both exchanges whatever happened to it locally, so that a failure on
-    # one rank cannot leave the others waiting in a collective.
+
+def _agree_on_ipc_comm(make, want: bool, what: str):
+    """Set-up of a communicator over mapped peer buffers that either every rank ends up with or none:
+    allocate, swap handles, map the peers, run its self-test, vote.  Every rank takes part in all
+    three exchanges whatever happened to it locally, so that a failure on one rank cannot leave the
+    others waiting in a collective.  Returns the communicator, or None when any rank said no."""
+    world = get_world_size()
+    group = get_group() or dist.group.WORLD
     log = __import__("logging").getLogger(__name__)
-    handle = b""
-    if want_ipc:
+    comm, ok, handle = None, 0, b""
+    if want:
         try:
-            comm = IpcAllReduce(get_rank(), world, max_rows, max_n)
+            comm = make()
             handle = comm.handle()
         except Exception as e:
-            log.warning("one-shot all-reduce: no exchange buffer on rank %d: %r", get_rank(), e)
+            log.warning("%s: no exchange buffer on rank %d: %r", what, get_rank(), e)
             comm = None
     handles = [None] * world
     dist.all_gather_object(handles, handle, group=group)
@@ -112,25 +121,45 @@ def tensor_parallel_reducer(max_rows: int, max_n: int):
             comm.connect(handles)
             ok = 1
         except Exception as e:
-            log.warning("one-shot all-reduce: rank %d cannot map its peers: %r", get_rank(), e)
+            log.warning("%s: rank %d cannot map its peers: %r", what, get_rank(), e)
     mapped = [None] * world
     dist.all_gather_object(mapped, ok, group=group)
     if all(v == 1 for v in mapped):
-        # everybody mapped everybody: one known sum through the buffers before they are trusted
+        # everybody mapped everybody: one known exchange through the buffers before they are trusted
         if not comm.self_test():
-            log.warning("one-shot all-reduce: self-test failed on rank %d", get_rank())
+            log.warning("%s: self-test failed on rank %d", what, get_rank())
             ok = 0
     else:
         ok = 0
     votes = [None] * world
     dist.all_gather_object(votes, ok, group=group)
     if all(v == 1 for v in votes):
-        _st.reducer = comm
-    else:
-        if comm is not None:
-            comm.close()
-        _st.reducer = DistAllReduce(all_reduce)
-    return _st.reducer
+        return comm
+    if comm is not None:
+        comm.close()
+    return None
+
+
+def tensor_parallel_gatherer(max_rows: int, n_local: int):
+    """The object that collects the ranks' [bs, n_local] slices of the logits when the LM head is cut
+    by vocabulary rows (kernel/allreduce.py::IpcAllGather), or None: then the head stays whole on
+    every rank, as in the reference.  Only offered next to the one-shot all-reduce (the same mapped
+    buffers, the same links), and switched off by MVLLM_LM_HEAD_SHARD=0; all ranks get the same
+    answer (they vote).  One per process."""
+    from ..kernel.allreduce import MAX_ROWS, IpcAllGather, IpcAllReduce
+
+    world = get_world_size()
+    if world <= 1 or not isinstance(_st.reducer, IpcAllReduce):
+        return None
+    g = _st.gatherer
+    if g is not None and g.max_rows >= max_rows and g.max_n == n_local:
+        return g
+    if g is not None:
+        g.close()
+    want = (os.environ.get("MVLLM_LM_HEAD_SHARD", "1") != "0" and max_rows <= MAX_ROWS and n_local % 8 == 0)
+    _st.gatherer = _agree_on_ipc_comm(lambda: IpcAllGather(get_rank(), world, max_rows, n_local), want,
+                                      "logits all-gather")
+    return _st.gatherer
 
 
 def barrier():

@@ -253,9 +253,92 @@ __global__ __launch_bounds__(kArThreads) void allreduce_addnorm_kernel(ArArgs a)
     }
 }
 
+// ---- all-gather of [rows, n_local] bf16 slices into [rows, world * n_local] rows on every rank ------
+// For the LM head cut by vocabulary rows over the ranks: every rank computes the logits of its slice
+// and needs the whole row (greedy pick, sampler).  Same exchange as above - push into every rank's
+// buffer, raise a per-row epoch flag there, wait for the flags raised here - but nothing is summed:
+// rank r's slice lands at columns [r * n_local, (r + 1) * n_local) of slot e & 1 of every buffer, and
+// each rank then copies the finished row out of its own buffer into ordinary memory (`out`), which is
+// what the kernels behind it read.  One workgroup per row.
+//   buffer: flags [kArMaxRows][kArFlagStride] | data [2][max_rows][world * max_n] bf16
+struct AgArgs {
+    unsigned char* peers[kArMaxWorld];
+    int rank, world, max_rows, max_n;
+    unsigned int* epoch;
+    int* status;
+    unsigned long long timeout_ticks;
+    const uint16_t* in;
+    int64_t ld_in;
+    uint16_t* out;
+    int64_t ld_out;
+    int n_local;
+};
+constexpr int kAgThreads = 512;
+
+// 16 bytes to a peer's buffer at system scope in one store (the flags order it; nothing reads it
+// before they are up, so it need not be atomic)
+__device__ __forceinline__ void st16_system_wide(void* p, uint4 v) {
+    const u32x4_t d = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(d) : "memory");
+}
+
+__global__ __launch_bounds__(kAgThreads) void allgather_kernel(AgArgs a) {
+    __shared__ unsigned int s_epoch;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) s_epoch = a.epoch[row] + 1u;
+    __syncthreads();
+    const unsigned int e = s_epoch;
+    const size_t row_bytes = (size_t)a.world * a.max_n * 2;
+    const size_t base = kArFlagBytes + ((size_t)(e & 1u) * a.max_rows + row) * row_bytes;
+    const int nvec = a.n_local >> 3;
+    // ---- push my slice into every rank's row (my own included) ---------------------------------
+    for (int c = tid; c < nvec; c += kAgThreads) {
+        const uint4 v = ld16(a.in + (int64_t)row * a.ld_in + c * 8);
+        for (int p = 0; p < a.world; ++p)
+            st16_system_wide(a.peers[p] + base + ((size_t)a.rank * a.n_local + c * 8) * 2, v);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store performed before the flags go up
+    __syncthreads();
+    if (tid < a.world) {
+        unsigned int* f = reinterpret_cast<unsigned int*>(a.peers[tid]) + row * kArFlagStride + a.rank;
+        __hip_atomic_store(f, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned int* mf = reinterpret_cast<const unsigned int*>(a.peers[a.rank]) + row * kArFlagStride + tid;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+            const unsigned int v = __hip_atomic_load(mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if ((int)(v - e) >= 0) break;
+            if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+                __hip_atomic_store(a.status, 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+    __syncthreads();
+    // ---- the finished row out of my own buffer (system-scope loads: never from a cache) ---------
+    const unsigned char* own = a.peers[a.rank] + base;
+    const int total = a.world * nvec;
+    constexpr int kAhead = 4;   // loads in flight per thread
+    for (int c0 = tid; c0 < total; c0 += kAgThreads * kAhead) {
+        uint4 v[kAhead];
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+            const int c = min(c0 + j * kAgThreads, total - 1);
+            v[j] = ld16_system(own + (size_t)c * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < kAhead; ++j) {
+            const int c = c0 + j * kAgThreads;
+            if (c < total) st16(a.out + (int64_t)row * a.ld_out + (int64_t)c * 8, v[j]);
+        }
+    }
+    if (tid == 0) a.epoch[row] = e;
+}
+
 struct ArComm {
     int rank = 0, world = 1, device = 0;
     int max_rows = 0, max_n = 0;
+    bool gather = false;   // an all-gather communicator (mv_allgather_*): max_n = columns of ONE rank
     size_t bytes = 0;
     unsigned char* local = nullptr;
     unsigned char* peers[kArMaxWorld] = {};
@@ -279,18 +362,35 @@ extern "C" {
 
 size_t mv_allreduce_handle_bytes(void) { return sizeof(hipIpcMemHandle_t); }
 
+static int comm_init(int rank, int world, int max_rows, int max_n, bool gather, void** comm_out);
+
 int mv_allreduce_init(int rank, int world, int max_rows, int max_n, void** comm_out) {
     using namespace mv;
     if (!comm_out || world < 1 || world > kArMaxWorld || rank < 0 || rank >= world) return MV_ERR_INVALID_ARG;
     if (max_rows < 1 || max_rows > kArMaxRows || max_n < 8 || (max_n % 8) != 0 || max_n > kArMaxN)
         return MV_ERR_UNSUPPORTED;
+    return comm_init(rank, world, max_rows, max_n, false, comm_out);
+}
+
+int mv_allgather_init(int rank, int world, int max_rows, int n_local, void** comm_out) {
+    using namespace mv;
+    if (!comm_out || world < 1 || world > kArMaxWorld || rank < 0 || rank >= world) return MV_ERR_INVALID_ARG;
+    if (max_rows < 1 || max_rows > kArMaxRows || n_local < 8 || (n_local % 8) != 0 || n_local > (1 << 20))
+        return MV_ERR_UNSUPPORTED;
+    return comm_init(rank, world, max_rows, n_local, true, comm_out);
+}
+
+static int comm_init(int rank, int world, int max_rows, int max_n, bool gather, void** comm_out) {
+    using namespace mv;
     ArComm* c = new ArComm();
     c->rank = rank;
     c->world = world;
     c->max_rows = max_rows;
     c->max_n = max_n;
+    c->gather = gather;
     hipError_t e = hipGetDevice(&c->device);
     if (e != hipSuccess) { delete c; return ar_fail(e); }
+    // (the same size either way: 2 slots x max_rows rows of world x max_n columns)
     c->bytes = kArFlagBytes + (size_t)2 * world * max_rows * max_n * 2;
     // Uncached device memory: stores go straight to memory and loads come from it, on this GPU and
     // on the peers that map it (what a flag protocol between agents needs).
@@ -396,7 +496,7 @@ int mv_allreduce_addnorm(void* comm, const void* in, int64_t ld_in, const float*
     using namespace mv;
     if (!comm || rows <= 0 || n <= 0) return MV_ERR_INVALID_ARG;
     ArComm* c = (ArComm*)comm;
-    if (!c->connected) return MV_ERR_INVALID_ARG;
+    if (!c->connected || c->gather) return MV_ERR_INVALID_ARG;
     if ((in == nullptr) == (slabs == nullptr)) return MV_ERR_INVALID_ARG;   // exactly one source
     if (slabs && ksplit < 1) return MV_ERR_INVALID_ARG;
     if (rows > c->max_rows || n > c->max_n || (n % 8) != 0) return MV_ERR_UNSUPPORTED;
@@ -437,6 +537,36 @@ int mv_allreduce_addnorm(void* comm, const void* in, int64_t ld_in, const float*
     a.ld_normed = ld_normed;
     a.var_from_rounded = (norm_flags & MV_NORM_VAR_FROM_ROUNDED) ? 1 : 0;
     hipLaunchKernelGGL(allreduce_addnorm_kernel, dim3(rows), dim3(kArThreads), 0, (hipStream_t)stream, a);
+    return check_launch();
+}
+
+int mv_allgather_rows(void* comm, const void* in, int64_t ld_in, void* out, int64_t ld_out, int rows,
+                      int n_local, mv_stream_t stream) {
+    using namespace mv;
+    if (!comm || !in || !out || rows <= 0 || n_local <= 0) return MV_ERR_INVALID_ARG;
+    ArComm* c = (ArComm*)comm;
+    if (!c->connected || !c->gather) return MV_ERR_INVALID_ARG;
+    if (rows > c->max_rows || n_local > c->max_n || (n_local % 8) != 0) return MV_ERR_UNSUPPORTED;
+    if (!aligned16(in) || !aligned16(out) || (ld_in % 8) != 0 || (ld_out % 8) != 0 || ld_in < n_local ||
+        ld_out < (int64_t)c->world * n_local)
+        return MV_ERR_INVALID_ARG;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev != c->device) return MV_ERR_INVALID_ARG;
+    AgArgs a = {};
+    for (int p = 0; p < c->world; ++p) a.peers[p] = c->peers[p];
+    a.rank = c->rank;
+    a.world = c->world;
+    a.max_rows = c->max_rows;
+    a.max_n = c->max_n;
+    a.epoch = c->epoch;
+    a.status = c->status;
+    a.timeout_ticks = c->timeout_ticks;
+    a.in = (const uint16_t*)in;
+    a.ld_in = ld_in;
+    a.out = (uint16_t*)out;
+    a.ld_out = ld_out;
+    a.n_local = n_local;
+    hipLaunchKernelGGL(allgather_kernel, dim3(rows), dim3(kAgThreads), 0, (hipStream_t)stream, a);
     return check_launch();
 }
 

@@ -142,6 +142,66 @@ class IpcAllReduce:
             nv.MV_NORM_VAR_FROM_ROUNDED if var_from_rounded else 0, rows, n, nv.stream_ptr()))
 
 
+class IpcAllGather(IpcAllReduce):
+    """Communicator of the all-gather of [rows, n_local] slices (the logits of an LM head cut by
+    vocabulary rows): same buffers, handles, flags and time-out as the all-reduce, nothing summed."""
+
+    takes_slabs = False
+
+    def __init__(self, rank: int, world: int, max_rows: int, n_local: int,
+                 exchange: Optional[Callable[[bytes], List[bytes]]] = None):
+        L = nv.lib()
+        self.rank, self.world, self.max_rows, self.max_n = rank, world, max_rows, n_local
+        self._comm = ctypes.c_void_p()
+        nv.check("mv_allgather_init", L.mv_allgather_init(rank, world, max_rows, n_local,
+                                                          ctypes.byref(self._comm)))
+        if world > 1 and exchange is not None:
+            try:
+                self.connect(exchange(self.handle()))
+            except Exception:
+                self.close()
+                raise
+
+    def gather(self, local: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """out[:, r * n_local : (r + 1) * n_local] = rank r's `local`, on every rank."""
+        assert local.is_cuda and local.dtype == torch.bfloat16 and local.dim() == 2 and local.stride(1) == 1
+        rows, n_local = local.shape
+        assert out.dtype == torch.bfloat16 and out.shape == (rows, self.world * n_local) and out.stride(1) == 1
+        ld_in = local.stride(0) if rows > 1 else max(n_local, local.stride(0))
+        ld_out = out.stride(0) if rows > 1 else max(self.world * n_local, out.stride(0))
+        nv.check("mv_allgather_rows", nv.lib().mv_allgather_rows(
+            self._comm, local.data_ptr(), ld_in, out.data_ptr(), ld_out, rows, n_local, nv.stream_ptr()))
+        return out
+
+    def self_test(self, timeout_ms: float = 3000.0) -> bool:
+        """Rank r sends r + 1 in every element of its slice; every rank must read q + 1 in slice q,
+        twice in a row (both data slots), with no wait timing out."""
+        import os
+        n = min(self.max_n, 1024)
+        self.set_timeout_ms(timeout_ms)
+        ok = True
+        try:
+            want = torch.arange(1, self.world + 1, dtype=torch.float32, device="cuda").repeat_interleave(n)[None]
+            for _ in range(2):
+                x = torch.full((1, n), float(self.rank + 1), dtype=torch.bfloat16, device="cuda")
+                out = torch.zeros(1, self.world * n, dtype=torch.bfloat16, device="cuda")
+                self.gather(x, out)
+                torch.cuda.synchronize()
+                ok = ok and bool((out.float() == want).all())
+            ok = ok and self.status() == 0
+        except Exception:
+            ok = False
+        default = float(os.environ.get("MVLLM_ALLREDUCE_TIMEOUT_MS", "10000") or 10000)
+        self.set_timeout_ms(default if default > 0 else 10000.0)
+        return ok
+
+    def all_reduce(self, x):
+        raise TypeError("an all-gather communicator sums nothing")
+
+    def addnorm(self, *a, **k):
+        raise TypeError("an all-gather communicator sums nothing")
+
+
 class DistAllReduce:
     """The reference's own sequence: all_reduce through torch.distributed, then the norm kernels."""
 

@@ -37,12 +37,14 @@ class SyntheticConfig:
     def intermediate_size(self) -> int:  # Qwen-1 meaning: gate + up
         return 2 * self.ffn_hidden_size
 
-    def weight_bytes(self, tp: int = 1) -> int:
-        """bf16 bytes one decode step streams per GPU: sharded layers + replicated LM head."""
+    def weight_bytes(self, tp: int = 1, head_sharded: bool = False) -> int:
+        """bf16 bytes one decode step streams per GPU: sharded layers + the LM head (replicated as in
+        the reference, or 1/tp of it when it is cut by vocabulary rows)."""
         h, d = self.hidden_size, self.head_dim
         per_layer = h * (self.num_attention_heads + 2 * self.num_key_value_heads) * d \
             + self.num_attention_heads * d * h + 3 * h * self.ffn_hidden_size
-        return 2 * (self.num_hidden_layers * per_layer // tp + h * self.vocab_size)
+        head = h * self.vocab_size // (tp if head_sharded else 1)
+        return 2 * (self.num_hidden_layers * per_layer // tp + head)
 
     def kv_bytes_per_token(self, tp: int = 1) -> int:
         """bf16 K+V bytes one cached token occupies per GPU over all layers."""

@@ -207,3 +207,94 @@ def test_ranks_sharing_one_gpu_agree_and_match_the_rank_ordered_sum(world):
     for rep in range(5):
         for i in range(4):
             assert torch.equal(next(it), _expected_sum(world, 4, 4096, 30 + i)), (rep, i)
+
+
+def _gather_worker(rank, world, port, out_q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), MVLLM_DIST_BACKEND="gloo", MVLLM_ALLREDUCE_TIMEOUT_MS="20000")
+    sys.path.insert(0, ROOT)
+    import ctypes
+
+    import micro_vllm_amd  # noqa: F401
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.core import parallel_config as pc
+    from micro_vllm_amd.kernel.allreduce import IpcAllGather, IpcAllReduce
+
+    torch.cuda.set_device(0)
+    pc.setup()
+    red = pc.tensor_parallel_reducer(16, 4096)           # the gatherer is only offered next to it
+    n_local = 16032                                      # 128256 / 8: the 8B vocabulary cut eight ways
+    gat = pc.tensor_parallel_gatherer(16, n_local)
+    res = {"ipc": isinstance(red, IpcAllReduce) and isinstance(gat, IpcAllGather)}
+    if not res["ipc"]:
+        out_q.put((rank, res))
+        return
+    outs = []
+    # different row counts and slice widths back to back, the all-reduce in between (as a step does)
+    for seed, (rows, n) in enumerate([(1, n_local), (16, n_local), (3, 256), (1, n_local), (5, 1000)]):
+        x = _partial(rank, rows, n, 100 + seed).to(DEV)
+        out = torch.full((rows, world * n + 8), 7.0, dtype=torch.bfloat16, device=DEV)
+        gat.gather(x, out[:, :world * n])
+        red.all_reduce(torch.zeros(1, 256, dtype=torch.bfloat16, device=DEV))
+        outs.append(out.cpu())
+    # captured and replayed: epochs keep growing, both data slots come round
+    x = torch.empty(4, n_local, dtype=torch.bfloat16, device=DEV)
+    out = torch.zeros(4, world * n_local, dtype=torch.bfloat16, device=DEV)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        gat.gather(x, out)
+        side.synchronize()
+        nv.check("begin", nv.lib().mv_graph_begin_capture(side.cuda_stream))
+        gat.gather(x, out)
+        h = ctypes.c_void_p()
+        nv.check("end", nv.lib().mv_graph_end_capture(side.cuda_stream, ctypes.byref(h)))
+        for rep in range(5):
+            x.copy_(_partial(rank, 4, n_local, 200 + rep).to(DEV))
+            nv.check("launch", nv.lib().mv_graph_launch(h, side.cuda_stream))
+            side.synchronize()
+            outs.append(out.cpu().clone())
+        nv.lib().mv_graph_destroy(h)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    res["status"] = max(red.status(), gat.status())
+    res["outs"] = [o.view(torch.int16).numpy() for o in outs]
+    pc.barrier()
+    out_q.put((rank, res))
+    gat.close()
+    red.close()
+    import torch.distributed as dist
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_all_gather_of_logit_slices_among_ranks_sharing_one_gpu(world):
+    """Every rank ends with every rank's slice at that rank's columns, bit for bit, nothing written
+    past the row, eager and under graph replay."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, res = q.get(timeout=240)
+        got[r] = res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(got[r]["ipc"] for r in range(world)), "the communicators over mapped buffers did not come up"
+    assert all(got[r]["status"] == 0 for r in range(world)), "a rank timed out waiting for a peer"
+    outs = {r: [torch.from_numpy(o).view(torch.bfloat16) for o in got[r]["outs"]] for r in range(world)}
+    n_local = 16032
+    for r in range(world):
+        it = iter(outs[r])
+        for seed, (rows, n) in enumerate([(1, n_local), (16, n_local), (3, 256), (1, n_local), (5, 1000)]):
+            o = next(it)
+            want = torch.cat([_partial(q_, rows, n, 100 + seed) for q_ in range(world)], dim=1)
+            assert torch.equal(o[:, :world * n], want), (r, seed)
+            assert torch.all(o[:, world * n:] == 7.0), "wrote past the row"
+        for rep in range(5):
+            want = torch.cat([_partial(q_, 4, n_local, 200 + rep) for q_ in range(world)], dim=1)
+            assert torch.equal(next(it), want), (r, rep)

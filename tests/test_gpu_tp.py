@@ -50,6 +50,8 @@ def _worker(rank, world, port, shape, fused, bs, mode, graph, out_q):
                               max_batch_size=16, fused=fused)
     assert runner.world_size == world and runner.rank == rank
     assert isinstance(runner._reducer, IpcAllReduce) == (mode == "ipc")
+    # next to the one-shot all-reduce the LM head is cut by vocabulary rows and the logits are gathered
+    assert (runner._gatherer is not None) == (mode == "ipc")
     mgr = KVCacheManager(n_pages, 256, cfg.num_hidden_layers, hkv, cfg.head_dim, dtype=torch.bfloat16,
                          device=dev, max_tokens=1024, max_batch_size=16)
     g = torch.Generator().manual_seed(5)
@@ -76,6 +78,8 @@ def _worker(rank, world, port, shape, fused, bs, mode, graph, out_q):
         replay_equal = bool(torch.equal(again, logits))
     bt = mgr._block_table_buffer[:bs].cpu()
     status = runner._reducer.status()
+    if runner._gatherer is not None:
+        status = max(status, runner._gatherer.status())
     pc.barrier()
     out_q.put((rank, logits.numpy(), bt.numpy(), replay_equal, status))
     runner._reducer.close()
