@@ -194,7 +194,9 @@ def test_engine_soak_many_ragged_requests(mv):
         eng.scheduler.running_sequences.clear()
 
 
-@pytest.mark.parametrize("scheme,shape,bias", [("llama", "tiny-d128", False), ("qwen", "tiny-mha", True)])
+@pytest.mark.parametrize("scheme,shape,bias", [("llama", "tiny-d128", False), ("qwen", "tiny-mha", True),
+                                               # Qwen2-like: q / k / v biases, 7 query heads on one kv head
+                                               ("llama", "tiny-gqa7", True)])
 def test_engine_from_a_checkpoint_directory_equals_engine_from_the_model_object(mv, tmp_path, scheme, shape, bias):
     """`InferenceEngine(model_path=...)` (core/engine.py:45-47, core/model_loader.py:6): the
     safetensors directory is read parameter by parameter and must give the very same greedy

@@ -42,7 +42,8 @@ def _same_model(a, b):
 
 @pytest.mark.parametrize("scheme,shape,bias,shards", [
     ("qwen", "tiny-mha", True, 1), ("qwen", "tiny-mha", True, 3),
-    ("llama", "tiny-gqa", False, 1), ("llama", "tiny-gqa", True, 2), ("llama", "tiny-d128", False, 4)])
+    ("llama", "tiny-gqa", False, 1), ("llama", "tiny-gqa", True, 2), ("llama", "tiny-d128", False, 4),
+    ("llama", "tiny-gqa7", True, 2)])
 def test_round_trip_is_bit_identical(tmp_path, scheme, shape, bias, shards):
     cfg = dataclasses.replace(SHAPES[shape], rope_theta=500000.0 if scheme == "llama" else 10000.0)
     src = build_synthetic_model(cfg, qkv_bias=bias, norm_jitter=0.1)
