@@ -16,7 +16,7 @@ dst = os.path.join(ROOT, "profiles")
 py = sys.executable
 
 shutil.copy(os.path.join(src, "trace", f"{tag}_kernel_stats.csv"), os.path.join(dst, f"{tag}_bench_kernel_stats.csv"))
-out = subprocess.run([py, os.path.join(ROOT, "tools", "trace_summary.py"), os.path.join(src, "trace", f"{tag}_kernel_trace.csv")],
+out = subprocess.run([py, os.path.join(ROOT, "tools", "trace_summary.py"), os.path.join(src, "trace", f"{tag}_kernel_trace.csv"), "--tail", "1.0"],   # every leg of the bench line
                      capture_output=True, text=True, check=True).stdout
 open(os.path.join(dst, f"{tag}_bench_trace_summary.txt"), "w").write(out)
 line = [l for l in open(os.path.join(src, "trace_bench.json")) if l.startswith("{")][-1]
