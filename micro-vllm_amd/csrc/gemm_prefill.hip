@@ -87,11 +87,12 @@ static __device__ unsigned long long g_stamp[4 * 512];
 
 // One wave's 64 (n) x 128 (m) block of accumulators to memory, with the projection epilogue:
 // acc[i][t][j] = C[n = 16 (nt0+i) + 4q + j][m = m0 + 16 t + r]
-__device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_t (&acc)[kPNT][kPMT], int nt0,
+template <int NT>
+__device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_t (&acc)[NT][kPMT], int nt0,
                                                 int m0, int ks, int r, int q) {
     const bool sw = (a.flags & MV_GEMM_SWIGLU) != 0, of32 = (a.flags & MV_GEMM_OUT_F32) != 0;
 #pragma unroll
-    for (int i = 0; i < kPNT; ++i) {
+    for (int i = 0; i < NT; ++i) {
         const int nt = nt0 + i;
         if (nt >= a.nt) continue;  // uniform
         const int n0 = nt * 16 + q * 4;
@@ -328,6 +329,7 @@ constexpr int kWM = 256, kWN = 256;
 constexpr int kWXSlot = 32768, kWWSlot = 16384;
 constexpr int kWLds = 3 * kWXSlot + 4 * kWWSlot;
 
+template <int NT>
 __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     unsigned char* const xring = lds;
@@ -356,7 +358,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     const int mb = band * a.mband + j % rows;
     if (nb >= a.nblocks || nbl >= a.nb_per_xcd) return;
     const int m0 = mb * kWM;
-    const int ntb = nb * (kWN / 16);
+    const int ntb = nb * (4 * NT);
     const int nstage = nkt >> 1;
 
     // ---- copy sources of this wave: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles likewise.
@@ -400,12 +402,12 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     // fragment reads: per-lane byte offsets inside a slot
     const int xoff0 = (wm * 8) * 2048 + r * 128 + (((0 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 0
     const int xoff1 = (wm * 8) * 2048 + r * 128 + (((4 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 1
-    const int woff = (wn * 4) * 1024 + lane * 16;
-    auto read_frags = [&](bf16x8_t(&wf)[kPNT], bf16x8_t(&xf)[kPMT], int kt) {
+    const int woff = (wn * NT) * 1024 + lane * 16;
+    auto read_frags = [&](bf16x8_t(&wf)[NT], bf16x8_t(&xf)[kPMT], int kt) {
 #if defined(MV_EXP_MFMA_ONLY) || defined(MV_EXP_NO_FRAG_READ)
         // timing experiment only: operands made up in registers, nothing read
 #pragma unroll
-        for (int i = 0; i < kPNT; ++i) wf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(lane * 77 + kt, i * 0x3f803f80u, kt * 0x01010101u, 0x3c003c00u));
+        for (int i = 0; i < NT; ++i) wf[i] = __builtin_bit_cast(bf16x8_t, make_uint4(lane * 77 + kt, i * 0x3f803f80u, kt * 0x01010101u, 0x3c003c00u));
 #pragma unroll
         for (int t = 0; t < kPMT; ++t) xf[t] = __builtin_bit_cast(bf16x8_t, make_uint4(lane * 31 + t, kt * 0x00810081u, 0x3f003f00u + t, 0x3d803d80u));
         return;
@@ -414,16 +416,16 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
         const unsigned char* wp = wring + (kt & 3) * kWWSlot + woff;
         const unsigned char* xp = xring + (st % 3) * kWXSlot + ((kt & 1) ? xoff1 : xoff0);
 #pragma unroll
-        for (int i = 0; i < kPNT; ++i)
+        for (int i = 0; i < NT; ++i)
             wf[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + i * 1024));
 #pragma unroll
         for (int t = 0; t < kPMT; ++t)
             xf[t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp + t * 2048));
     };
 
-    f32x4_t acc[kPNT][kPMT];
+    f32x4_t acc[NT][kPMT];
 #pragma unroll
-    for (int i = 0; i < kPNT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int t = 0; t < kPMT; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     copy_x(0, 0);
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    bf16x8_t wA[kPNT], xA[kPMT], wB[kPNT], xB[kPMT];
+    bf16x8_t wA[NT], xA[kPMT], wB[NT], xB[kPMT];
     read_frags(wA, xA, 0);
     __syncthreads();   // every wave holds k-tile 0 before its slot is written again
 
@@ -455,7 +457,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
             copy(wbase[j] + (int64_t)ktc * 1024, wlane, w_lds + (kt & 3) * kWWSlot + (2 * wid + j) * 1024);
         }
     };
-    auto ktile = [&](bf16x8_t(&wc)[kPNT], bf16x8_t(&xc)[kPMT], bf16x8_t(&wnx)[kPNT], bf16x8_t(&xnx)[kPMT], int kt,
+    auto ktile = [&](bf16x8_t(&wc)[NT], bf16x8_t(&xc)[kPMT], bf16x8_t(&wnx)[NT], bf16x8_t(&xnx)[kPMT], int kt,
                      bool odd) {
         const int ktn = min(kt + 1, nkt - 1);
         const unsigned char* wp = wring + (ktn & 3) * kWWSlot + woff;
@@ -470,7 +472,8 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
 #ifndef MV_EXP_NO_FRAG_READ
             if (t < 2) {
                 wnx[2 * t] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + (2 * t) * 1024));
-                wnx[2 * t + 1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + (2 * t + 1) * 1024));
+                if (2 * t + 1 < NT)
+                    wnx[2 * t + 1] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(wp + (2 * t + 1) * 1024));
             } else if (t < 6) {
                 xnx[2 * t - 4] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp + (2 * t - 4) * 2048));
                 xnx[2 * t - 3] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xp + (2 * t - 3) * 2048));
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < kPNT; ++i)
+            for (int i = 0; i < NT; ++i)
                 MV_MFMA(acc[i][t], wc[i], xc[t]);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -495,8 +498,8 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after this workgroup is gone
 
-    if (ntb + wn * 4 >= a.nt) return;
-    store_wave_tile(a, acc, ntb + wn * 4, m0 + wm * 128, ks, r, q);
+    if (ntb + wn * NT >= a.nt) return;
+    store_wave_tile<NT>(a, acc, ntb + wn * NT, m0 + wm * 128, ks, r, q);
 }
 
 }  // namespace mv
@@ -543,22 +546,49 @@ static int prefill_ksplit(int m, int n, int kt) {
 // Since the slab reduction reads 16 bytes a lane (15 us for 67 MB of slabs where it took 43) the same
 // holds from k = 4096: the O projection at 1536 tokens 85 -> 67 us, at 2048 tokens 93 -> 89.
 // MVLLM_PREFILL_WIDE = 0 / 1 forces the choice of form (read once).
+//
+// Width of a wide tile: 256 columns (four n-tiles per wave) or 192 (three).  A CU holds one tile at a
+// time and an XCD's 32 CUs take that XCD's tiles in rounds, so a product costs rounds x tile width; the
+// narrower tile does a twelfth more operand traffic per multiply-add and has fewer MFMAs to hide
+// each copy and fragment read behind (priced at 12 %: the gate/up projection at 2048 tokens, four
+// rounds of 256 columns or five of 192, measured 425 against 441 us) and wins where it fills a round
+// the wider one leaves part empty - the QKV projection of the 8B shape (6144 columns) at 4096 tokens
+// is 384 tiles of 256 columns, two rounds with the second half empty, or 512 tiles of 192 in two
+// full rounds of three quarters the length: 194 -> 171 us; at 1536 tokens 106 -> 95.
+// MVLLM_PREFILL_WIDE_NT = 3 / 4 forces the width (read once).
 struct PrefillPlan {
     bool wide;
     int ks;
+    int ntw;   // wide form: n-tiles per wave (4 or 3)
 };
+static int wide_tile_strips(int m, int n) {
+    static const int forced = [] {
+        const char* e = getenv("MVLLM_PREFILL_WIDE_NT");
+        return e && *e ? atoi(e) : 0;
+    }();
+    if (forced == 3 || forced == 4) return forced;
+    const long mblocks = (m + kWM - 1) / kWM;
+    const int per_xcd = std::max(1, num_cus() / 8);
+    double cost[2];
+    for (int ntw = 3; ntw <= 4; ++ntw) {
+        const long nblocks = (n + 64 * ntw - 1) / (64 * ntw);
+        const long rounds = (((nblocks + 7) / 8) * mblocks + per_xcd - 1) / per_xcd;
+        cost[ntw - 3] = (double)rounds * ntw * (ntw == 3 ? 1.12 : 1.0);
+    }
+    return cost[0] < cost[1] ? 3 : 4;
+}
 static PrefillPlan prefill_plan(int m, int n, int kt) {
     static const int forced = [] {
         const char* e = getenv("MVLLM_PREFILL_WIDE");
         return e && *e ? atoi(e) : -1;
     }();
     const int narrow_ks = prefill_ksplit(m, n, kt);
-    if (kt < 8 || forced == 0) return {false, narrow_ks};
+    if (kt < 8 || forced == 0) return {false, narrow_ks, 4};
     const long tiles = (long)((m + kWM - 1) / kWM) * ((n + kWN - 1) / kWN);
     const int cus = num_cus();
-    if (forced < 0 && kt >= 128 && kt % 4 == 0 && 8 * tiles >= 3L * cus && 2 * tiles <= cus) return {true, 2};
-    if (narrow_ks == 1 && (forced == 1 || 2 * tiles >= cus)) return {true, 1};
-    return {false, narrow_ks};
+    if (forced < 0 && kt >= 128 && kt % 4 == 0 && 8 * tiles >= 3L * cus && 2 * tiles <= cus) return {true, 2, 4};
+    if (narrow_ks == 1 && (forced == 1 || 2 * tiles >= cus)) return {true, 1, wide_tile_strips(m, n)};
+    return {false, narrow_ks, 4};
 }
 }  // namespace mv
 
@@ -572,7 +602,8 @@ extern "C" size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k) {
 extern "C" int mv_gemm_prefill_form(int m, int n, int k) {
     using namespace mv;
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
-    return prefill_plan(m, n, k / 32).wide ? 1 : 0;
+    const PrefillPlan plan = prefill_plan(m, n, k / 32);
+    return !plan.wide ? 0 : plan.ks == 1 && plan.ntw == 3 ? 2 : 1;
 }
 
 extern "C" int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
@@ -633,11 +664,13 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
     }
     a.ktps = a.kt / a.ksplit;
     if (wide) {
-        static LdsOptIn lds_done;
-        int rc = ensure_dynamic_lds((const void*)gemm_prefill_wide_kernel, kWLds, lds_done);
+        static LdsOptIn lds_done[2];
+        const int ntw = a.ksplit == 1 ? plan.ntw : 4;
+        const void* kernel = ntw == 3 ? (const void*)gemm_prefill_wide_kernel<3> : (const void*)gemm_prefill_wide_kernel<4>;
+        int rc = ensure_dynamic_lds(kernel, kWLds, lds_done[ntw - 3]);
         if (rc != MV_OK) return rc;
         a.mblocks = (m + kWM - 1) / kWM;
-        a.nblocks = (n + kWN - 1) / kWN;
+        a.nblocks = (n + 64 * ntw - 1) / (64 * ntw);
         a.nb_per_xcd = (a.nblocks + 7) / 8;
         a.mband = a.mblocks < 8 ? a.mblocks : 8;
         if (const char* e = getenv("MVLLM_PREFILL_MBAND")) {   // experiments: 0 = one band (the whole column)
@@ -646,7 +679,10 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
         }
         const long wgrid = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
         if (wgrid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
-        hipLaunchKernelGGL(gemm_prefill_wide_kernel, dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
+        if (ntw == 3)
+            hipLaunchKernelGGL(gemm_prefill_wide_kernel<3>, dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(gemm_prefill_wide_kernel<4>, dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
         rc = check_launch();
         if (rc != MV_OK || a.ksplit == 1) return rc;
         return launch_wgemm_finalize(a.partial, a.ksplit, m, n, flags, a.bias, a.residual, ld_res, y, ldy,
