@@ -220,9 +220,9 @@ int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const vo
 /* Which form a call of that shape takes on the current device (for tests and tools; no counterpart
  * in the reference): 0 = 128 x 256 tiles, two workgroups per CU, weights straight into registers;
  * 1 = 256 x 256 tiles, one workgroup per CU, both operands through LDS (taken when its tiles fill
- * at least half the CUs; MVLLM_PREFILL_WIDE=0/1 forces the choice for a process); 2 = the same with
- * tiles of 192 columns, where those fill the CUs in fewer or fuller rounds (MVLLM_PREFILL_WIDE_NT=3/4
- * forces the width). */
+ * at least half the CUs; MVLLM_PREFILL_WIDE=0/1 forces the choice for a process); 2 and 3 = the same
+ * with tiles of 192 and of 224 columns, where those fill the CUs in fewer or fuller rounds
+ * (MVLLM_PREFILL_WIDE_STRIPS=12/14/16 forces the width, in 16-column strips). */
 int mv_gemm_prefill_form(int m, int n, int k);
 
 /* ---------------------------------------------------- paged attention */

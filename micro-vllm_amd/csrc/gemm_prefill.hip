@@ -329,16 +329,15 @@ constexpr int kWM = 256, kWN = 256;
 constexpr int kWXSlot = 32768, kWWSlot = 16384;
 constexpr int kWLds = 3 * kWXSlot + 4 * kWWSlot;
 
+// One wave's share of a tile: NT n-tiles from strip `wcol` of a block that is `width` strips wide.
 template <int NT>
-__global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+__device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds, int wid, int wm, int wcol,
+                                          int width) {
     unsigned char* const xring = lds;
     unsigned char* const wring = lds + 3 * kWXSlot;
 
     const int lane = threadIdx.x & 63;
-    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
-    const int wn = wid & 3, wm = wid >> 2;
 
     // blockIdx -> tile.  An XCD (blockIdx mod 8) owns a contiguous range of n-blocks and walks it in
     // bands of `mband` m-blocks: m fastest inside the band, then n, then the next band - so the 32
@@ -358,7 +357,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     const int mb = band * a.mband + j % rows;
     if (nb >= a.nblocks || nbl >= a.nb_per_xcd) return;
     const int m0 = mb * kWM;
-    const int ntb = nb * (4 * NT);
+    const int ntb = nb * width;
     const int nstage = nkt >> 1;
 
     // ---- copy sources of this wave: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles likewise.
@@ -402,7 +401,7 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     // fragment reads: per-lane byte offsets inside a slot
     const int xoff0 = (wm * 8) * 2048 + r * 128 + (((0 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 0
     const int xoff1 = (wm * 8) * 2048 + r * 128 + (((4 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 1
-    const int woff = (wn * NT) * 1024 + lane * 16;
+    const int woff = wcol * 1024 + lane * 16;
     auto read_frags = [&](bf16x8_t(&wf)[NT], bf16x8_t(&xf)[kPMT], int kt) {
 #if defined(MV_EXP_MFMA_ONLY) || defined(MV_EXP_NO_FRAG_READ)
         // timing experiment only: operands made up in registers, nothing read
@@ -498,8 +497,32 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after this workgroup is gone
 
-    if (ntb + wn * NT >= a.nt) return;
-    store_wave_tile<NT>(a, acc, ntb + wn * NT, m0 + wm * 128, ks, r, q);
+    if (ntb + wcol >= a.nt) return;
+    store_wave_tile<NT>(a, acc, ntb + wcol, m0 + wm * 128, ks, r, q);
+}
+
+// Tile width: wave column c of wave row wm takes NTA n-tiles when c + wm is even and NTB otherwise, so
+// a block is 2 (NTA + NTB) strips wide - 16, 14 or 12 - and the two waves that share a SIMD (same
+// column, the two rows) always have NTA + NTB n-tiles between them: the matrix pipes stay evenly
+// loaded at the odd width too.  Both kinds of wave run the same copies, waits and barriers per
+// k-tile; only the number of fragments and MFMAs differs.
+template <int NTA, int NTB>
+__global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wid & 3, wm = wid >> 2;
+    constexpr int kWidth = 2 * (NTA + NTB);
+    if constexpr (NTA == NTB) {
+        wide_tile<NTA>(a, lds, wid, wm, wn * NTA, kWidth);
+    } else {
+        // row 0: A B A B, row 1: B A B A
+        const int first = wm ? NTB : NTA;
+        const int wcol = (wn >> 1) * (NTA + NTB) + ((wn & 1) ? first : 0);
+        if (((wn + wm) & 1) == 0)
+            wide_tile<NTA>(a, lds, wid, wm, wcol, kWidth);
+        else
+            wide_tile<NTB>(a, lds, wid, wm, wcol, kWidth);
+    }
 }
 
 }  // namespace mv
@@ -547,35 +570,45 @@ static int prefill_ksplit(int m, int n, int kt) {
 // holds from k = 4096: the O projection at 1536 tokens 85 -> 67 us, at 2048 tokens 93 -> 89.
 // MVLLM_PREFILL_WIDE = 0 / 1 forces the choice of form (read once).
 //
-// Width of a wide tile: 256 columns (four n-tiles per wave) or 192 (three).  A CU holds one tile at a
-// time and an XCD's 32 CUs take that XCD's tiles in rounds, so a product costs rounds x tile width; the
-// narrower tile does a twelfth more operand traffic per multiply-add and has fewer MFMAs to hide
-// each copy and fragment read behind (priced at 12 %: the gate/up projection at 2048 tokens, four
-// rounds of 256 columns or five of 192, measured 425 against 441 us) and wins where it fills a round
-// the wider one leaves part empty - the QKV projection of the 8B shape (6144 columns) at 4096 tokens
-// is 384 tiles of 256 columns, two rounds with the second half empty, or 512 tiles of 192 in two
-// full rounds of three quarters the length: 194 -> 171 us; at 1536 tokens 106 -> 95.
-// MVLLM_PREFILL_WIDE_NT = 3 / 4 forces the width (read once).
+// Width of a wide tile: 16 strips (256 columns; four n-tiles per wave), 14 (224; four and three) or
+// 12 (192; three).  A CU holds one tile at a time and an XCD's 32 CUs take that XCD's tiles in
+// rounds, so a product costs rounds x tile width; a narrower tile does more operand traffic per
+// multiply-add and has fewer MFMAs to hide each copy and fragment read behind (priced at 12 %: the
+// gate/up projection at 2048 tokens, four rounds of 256 columns or five of 192, measured 425 against
+// 441 us) and wins where it fills a round the wider one leaves part empty - the QKV projection of the
+// 8B shape (6144 columns) at 4096 tokens is 384 tiles of 256 columns, two rounds with the second half
+// empty, or 512 tiles of 192 in two full rounds of three quarters the length: 194 -> 171 us; at 1536
+// tokens 106 -> 95.  The 224-column tile gains less than its width promises (priced at 10 %): the wave
+// with three n-tiles waits at every barrier for its SIMD partner with four, which then runs without a
+// partner to fill its issue gaps - gate/up (28672 columns = 128 such tiles per m-block) at 2048 tokens
+// 419 -> 415 us, at 3072 tokens 630 -> 605.  MVLLM_PREFILL_WIDE_STRIPS = 12 / 14 / 16 forces the
+// width (read once).
 struct PrefillPlan {
     bool wide;
     int ks;
-    int ntw;   // wide form: n-tiles per wave (4 or 3)
+    int strips;   // wide form: 16-column strips per tile (16, 14 or 12)
 };
 static int wide_tile_strips(int m, int n) {
     static const int forced = [] {
-        const char* e = getenv("MVLLM_PREFILL_WIDE_NT");
+        const char* e = getenv("MVLLM_PREFILL_WIDE_STRIPS");
         return e && *e ? atoi(e) : 0;
     }();
-    if (forced == 3 || forced == 4) return forced;
+    if (forced == 12 || forced == 14 || forced == 16) return forced;
     const long mblocks = (m + kWM - 1) / kWM;
+    const long nt = n / 16;
     const int per_xcd = std::max(1, num_cus() / 8);
-    double cost[2];
-    for (int ntw = 3; ntw <= 4; ++ntw) {
-        const long nblocks = (n + 64 * ntw - 1) / (64 * ntw);
+    int best = 16;
+    double best_cost = 1e30;
+    for (int w = 16; w >= 12; w -= 2) {
+        const long nblocks = (nt + w - 1) / w;
         const long rounds = (((nblocks + 7) / 8) * mblocks + per_xcd - 1) / per_xcd;
-        cost[ntw - 3] = (double)rounds * ntw * (ntw == 3 ? 1.12 : 1.0);
+        const double cost = (double)rounds * w * (w == 16 ? 1.0 : w == 14 ? 1.10 : 1.12);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = w;
+        }
     }
-    return cost[0] < cost[1] ? 3 : 4;
+    return best;
 }
 static PrefillPlan prefill_plan(int m, int n, int kt) {
     static const int forced = [] {
@@ -583,12 +616,12 @@ static PrefillPlan prefill_plan(int m, int n, int kt) {
         return e && *e ? atoi(e) : -1;
     }();
     const int narrow_ks = prefill_ksplit(m, n, kt);
-    if (kt < 8 || forced == 0) return {false, narrow_ks, 4};
+    if (kt < 8 || forced == 0) return {false, narrow_ks, 16};
     const long tiles = (long)((m + kWM - 1) / kWM) * ((n + kWN - 1) / kWN);
     const int cus = num_cus();
-    if (forced < 0 && kt >= 128 && kt % 4 == 0 && 8 * tiles >= 3L * cus && 2 * tiles <= cus) return {true, 2, 4};
+    if (forced < 0 && kt >= 128 && kt % 4 == 0 && 8 * tiles >= 3L * cus && 2 * tiles <= cus) return {true, 2, 16};
     if (narrow_ks == 1 && (forced == 1 || 2 * tiles >= cus)) return {true, 1, wide_tile_strips(m, n)};
-    return {false, narrow_ks, 4};
+    return {false, narrow_ks, 16};
 }
 }  // namespace mv
 
@@ -603,7 +636,7 @@ extern "C" int mv_gemm_prefill_form(int m, int n, int k) {
     using namespace mv;
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
     const PrefillPlan plan = prefill_plan(m, n, k / 32);
-    return !plan.wide ? 0 : plan.ks == 1 && plan.ntw == 3 ? 2 : 1;
+    return !plan.wide ? 0 : plan.ks > 1 || plan.strips == 16 ? 1 : plan.strips == 12 ? 2 : 3;
 }
 
 extern "C" int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
@@ -664,13 +697,15 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
     }
     a.ktps = a.kt / a.ksplit;
     if (wide) {
-        static LdsOptIn lds_done[2];
-        const int ntw = a.ksplit == 1 ? plan.ntw : 4;
-        const void* kernel = ntw == 3 ? (const void*)gemm_prefill_wide_kernel<3> : (const void*)gemm_prefill_wide_kernel<4>;
-        int rc = ensure_dynamic_lds(kernel, kWLds, lds_done[ntw - 3]);
+        static LdsOptIn lds_done[3];
+        const int strips = a.ksplit == 1 ? plan.strips : 16;
+        const void* kernel = strips == 12   ? (const void*)gemm_prefill_wide_kernel<3, 3>
+                             : strips == 14 ? (const void*)gemm_prefill_wide_kernel<4, 3>
+                                            : (const void*)gemm_prefill_wide_kernel<4, 4>;
+        int rc = ensure_dynamic_lds(kernel, kWLds, lds_done[(strips - 12) / 2]);
         if (rc != MV_OK) return rc;
         a.mblocks = (m + kWM - 1) / kWM;
-        a.nblocks = (n + 64 * ntw - 1) / (64 * ntw);
+        a.nblocks = (a.nt + strips - 1) / strips;
         a.nb_per_xcd = (a.nblocks + 7) / 8;
         a.mband = a.mblocks < 8 ? a.mblocks : 8;
         if (const char* e = getenv("MVLLM_PREFILL_MBAND")) {   // experiments: 0 = one band (the whole column)
@@ -679,10 +714,12 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
         }
         const long wgrid = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
         if (wgrid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
-        if (ntw == 3)
-            hipLaunchKernelGGL(gemm_prefill_wide_kernel<3>, dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
+        if (strips == 12)
+            hipLaunchKernelGGL((gemm_prefill_wide_kernel<3, 3>), dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
+        else if (strips == 14)
+            hipLaunchKernelGGL((gemm_prefill_wide_kernel<4, 3>), dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
         else
-            hipLaunchKernelGGL(gemm_prefill_wide_kernel<4>, dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
+            hipLaunchKernelGGL((gemm_prefill_wide_kernel<4, 4>), dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
         rc = check_launch();
         if (rc != MV_OK || a.ksplit == 1) return rc;
         return launch_wgemm_finalize(a.partial, a.ksplit, m, n, flags, a.bias, a.residual, ld_res, y, ldy,

@@ -53,6 +53,7 @@ def test_prefill_forms(mv):
     # projections: the 256 x 256 form once its tiles fill half the CUs and k is not cut
     assert L.mv_gemm_prefill_form(4096, 6144, 4096) == 2       # 192-column tiles: two full rounds
     assert L.mv_gemm_prefill_form(4096, 28672, 4096) == 1      # 256-column tiles: seven rounds against ten
+    assert L.mv_gemm_prefill_form(2048, 28672, 4096) == 3      # 224-column tiles: four full rounds, not 3.5
     assert L.mv_gemm_prefill_form(2048, 4096, 4096) == 1       # 128 tiles
     assert L.mv_gemm_prefill_form(1024, 4096, 4096) == 0       # 64 tiles
     assert L.mv_gemm_prefill_form(128, 4096, 4096) == 0 and L.mv_gemm_prefill_workspace_bytes(128, 4096, 4096) > 0
