@@ -160,7 +160,7 @@ def projection_timing(runner, bs, layers, reps=20):
     figure is the dominant kernel's own; the ~0.2 us between graph nodes is inside it."""
     import ctypes
     from micro_vllm_amd import _native as nv
-    from micro_vllm_amd.kernel.linear import chain_phase, decode_chain, wgemm, wgemm_norm, wgemm_postnorm
+    from micro_vllm_amd.kernel.linear import chain_phase, decode_chain, wgemm, wgemm_norm, wgemm_postnorm, wgemm_slabs
 
     tr = runner.model.transformer
     chained = bs <= 4 and bool(runner._chain_ok.get(bs))
@@ -204,7 +204,10 @@ def projection_timing(runner, bs, layers, reps=20):
                            add_r=h, sum_out=resid, swiglu=True, workspace=ws)
                 wgemm(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs], residual=resid, workspace=ws)
             else:           # ModelGraphRunner._decode_batched
-                wgemm(normed, b.attn._qkv_w, runner._qkv[:bs], bias=b.attn._qkv_b, workspace=ws)
+                if runner.qkv_slabs:    # the slabs are added up by the attention kernel (not timed here)
+                    wgemm_slabs(normed, b.attn._qkv_w, ws)
+                else:
+                    wgemm(normed, b.attn._qkv_w, runner._qkv[:bs], bias=b.attn._qkv_b, workspace=ws, plan_slabs=True)
                 wgemm_postnorm(attn, b.attn._o, resid, b.ln_2.weight, b.ln_2.eps, normed, residual=h, workspace=ws)
                 wgemm(normed, b.mlp._gu, runner._swiglu_out[:bs], swiglu=True, workspace=ws)
                 wgemm_postnorm(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs], b.ln_1.weight, b.ln_1.eps,

@@ -272,6 +272,20 @@ int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, c
                          size_t workspace_bytes, int bs, int hq, int hkv, int d, int page,
                          int num_pages, float scale, int num_splits, mv_stream_t stream);
 
+/* mv_paged_attn_decode with q | k_new | v_new taken as the QKV projection left them when it was cut
+ * along k: qkv_slabs = fp32 [ksplit][bs][(Hq + 2 Hkv) D] (an MV_GEMM_SLABS call of mv_wgemm), whose
+ * sum in slab order, rounded to bf16, plus qkv_bias ([(Hq + 2 Hkv) D] bf16 or NULL) rounded again,
+ * is the row the projection's own slab reduction would have stored - bit for bit - so a decode
+ * step for more than four rows saves that launch.  Everything else as mv_paged_attn_decode.  No
+ * counterpart in the reference (its QKV projection is one cuBLAS call, core/layer/model_graph.py:
+ * 141-148). */
+int mv_paged_attn_decode_slabs(const void* qkv_slabs, int ksplit, const void* qkv_bias, void* k_cache,
+                               void* v_cache, const void* rot_cos, const void* rot_sin, int rot_max_pos,
+                               const int32_t* cache_seqlens, const int32_t* block_table, int bt_stride,
+                               void* out, void* workspace, size_t workspace_bytes, int bs, int hq, int hkv,
+                               int d, int page, int num_pages, float scale, int num_splits,
+                               mv_stream_t stream);
+
 /* mv_paged_attn_decode for callers that cannot allocate device memory (code under HIP stream
  * capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels and the same
  * results, bit for bit, with the split-KV workspace in an 8 MiB array that is part of the

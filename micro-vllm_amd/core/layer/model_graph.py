@@ -15,12 +15,13 @@ Differences that are deliberate:
     reference's separate ops round, and the fused and unfused paths agree bit for bit.
 """
 import logging
+import os
 from typing import Dict, List
 
 import torch
 
 from .. import parallel_config as pc
-from ..paged_attention import PagedAttention, paged_attn_decode
+from ..paged_attention import PagedAttention, paged_attn_decode, paged_attn_decode_slabs
 from ... import _native as nv
 from ...kernel.linear import (StreamedWeight, add_, chain_phase, decode_chain, embedding, gemm_workspace,
                               wgemm, wgemm_norm, wgemm_postnorm, wgemm_slabs)
@@ -106,6 +107,9 @@ class ModelGraphRunner:
             self.rank, self.world_size = tp_rank, tp_world
         self._reducer = reducer
         self.chain = chain
+        # batches of more than four rows: attention adds up the QKV projection's k-slabs itself
+        # (MVLLM_QKV_SLABS=0: the projection reduces them in a launch of its own, as before)
+        self.qkv_slabs = os.environ.get("MVLLM_QKV_SLABS", "1") != "0"
         self.num_heads = num_heads
         self.kv_num_heads = kv_num_heads
         self.intermediate_size = intermediate_size
@@ -240,7 +244,8 @@ class ModelGraphRunner:
             need = max([need] + [L.mv_wgemm_workspace_bytes(m, n, k) for m in range(1, max_b + 1)])
         # projections that hand k-slabs to the kernel after them: O and down (their slab reduction
         # carries a norm, or is the tensor-parallel reduction)
-        for n, k in ((self.hidden_dim, _b.attn._o.k), (self.hidden_dim, _b.mlp._d.k)):
+        # and QKV, whose slabs the attention kernel adds up
+        for n, k in ((self.hidden_dim, _b.attn._o.k), (self.hidden_dim, _b.mlp._d.k), (qkv_dim, self.hidden_dim)):
             need = max([need] + [L.mv_wgemm_postnorm_workspace_bytes(m, n, k) for m in range(1, max_b + 1)])
         self._gemm_ws = gemm_workspace(dev, max(need, 16))
         self._attn_ws = None
@@ -282,11 +287,12 @@ class ModelGraphRunner:
     def _qkv_proj(self, h, block, bs):
         rmsnorm_(h, block.ln_1.weight, self._normed[:bs], block.ln_1.eps)
         qkv_buf = self._qkv[:bs]
+        # bs > 4: k cut as in the batched step, whose attention adds the QKV slabs up itself
         if self.fused:
             wgemm(self._normed[:bs], block.attn._qkv_w, qkv_buf, bias=block.attn._qkv_b,
-                  workspace=self._gemm_ws)
+                  workspace=self._gemm_ws, plan_slabs=bs > 4)
         else:
-            wgemm(self._normed[:bs], block.attn._qkv_w, qkv_buf, workspace=self._gemm_ws)
+            wgemm(self._normed[:bs], block.attn._qkv_w, qkv_buf, workspace=self._gemm_ws, plan_slabs=bs > 4)
             if block.attn._qkv_b is not None:
                 add_(qkv_buf, block.attn._qkv_b)
         return qkv_buf
@@ -435,6 +441,32 @@ class ModelGraphRunner:
         """Fresh uniform numbers for the next step's draws (queued ahead of the step)."""
         self._samp_u[:bs].uniform_(0.0, 1.0, generator=generator)
 
+    def _qkv_attention(self, normed, block, layer_idx, bs, cache_manager):
+        """QKV projection of `normed` and attention over the pages -> [bs, Hq, D].  More than four
+        rows: the projection is cut along k and leaves its slabs in the workspace, which the
+        attention kernel adds up (with the bias) as it loads q, k and v - the same values, bit for
+        bit, as the projection's own slab reduction would have stored, without that launch."""
+        hq, hkv, d = self.num_heads, self.kv_num_heads, self.head_size
+        k_cache, v_cache = cache_manager.get(layer_idx)
+        seqlens = cache_manager._cache_seqlens_buffer[:bs]
+        table = cache_manager._block_table_buffer[:bs]
+        splits = self._splits_for(bs, cache_manager)
+        if bs > 4 and self.qkv_slabs:
+            ks = wgemm_slabs(normed, block.attn._qkv_w, self._gemm_ws)
+            return paged_attn_decode_slabs(
+                self._gemm_ws, ks, block.attn._qkv_b, hq, k_cache, v_cache, seqlens, table,
+                self.attention._cos_pool, self.attention._sin_pool, num_splits=splits,
+                out=self._attn[:bs], workspace=self._attn_ws)
+        # (k cut as the slab-leaving call cuts it: the same sums either way)
+        wgemm(normed, block.attn._qkv_w, self._qkv[:bs], bias=block.attn._qkv_b, workspace=self._gemm_ws,
+              plan_slabs=bs > 4)
+        qkv = self._qkv[:bs]
+        return paged_attn_decode(
+            qkv[:, :hq * d].unflatten(1, (hq, d)), qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)),
+            qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d)), k_cache, v_cache, seqlens, table,
+            self.attention._cos_pool, self.attention._sin_pool, num_splits=splits,
+            out=self._attn[:bs], workspace=self._attn_ws)
+
     def _decode_batched(self, h, bs, cache_manager):
         """bs > 4 on one GPU: the norm that follows the O and the down projection rides on their
         slab reduction (`wgemm_postnorm`), so a block is QKV, attention, O(+add+norm), gate/up,
@@ -447,17 +479,7 @@ class ModelGraphRunner:
         rmsnorm_(h, blocks[0].ln_1.weight, normed, blocks[0].ln_1.eps)
         for layer_idx in range(self.num_layers):
             block = blocks[layer_idx]
-            wgemm(normed, block.attn._qkv_w, self._qkv[:bs], bias=block.attn._qkv_b, workspace=ws)
-            hq, hkv, d = self.num_heads, self.kv_num_heads, self.head_size
-            qkv = self._qkv[:bs]
-            k_cache, v_cache = cache_manager.get(layer_idx)
-            attn = paged_attn_decode(
-                qkv[:, :hq * d].unflatten(1, (hq, d)), qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)),
-                qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d)), k_cache, v_cache,
-                cache_manager._cache_seqlens_buffer[:bs], cache_manager._block_table_buffer[:bs],
-                self.attention._cos_pool, self.attention._sin_pool,
-                num_splits=self._splits_for(bs, cache_manager), out=self._attn[:bs],
-                workspace=self._attn_ws)
+            attn = self._qkv_attention(normed, block, layer_idx, bs, cache_manager)
             # residual <- bf16(attn @ Wo^T + h); normed <- rmsnorm(that sum, unrounded) * ln_2
             wgemm_postnorm(attn.reshape(bs, -1), block.attn._o, self._residual[:bs], block.ln_2.weight,
                            block.ln_2.eps, normed, residual=h, workspace=ws)
@@ -546,16 +568,7 @@ class ModelGraphRunner:
         rmsnorm_(h, blocks[0].ln_1.weight, normed, blocks[0].ln_1.eps)
         for layer_idx in range(self.num_layers):
             block = blocks[layer_idx]
-            wgemm(normed, block.attn._qkv_w, self._qkv[:bs], bias=block.attn._qkv_b, workspace=ws)
-            qkv = self._qkv[:bs]
-            k_cache, v_cache = cache_manager.get(layer_idx)
-            attn = paged_attn_decode(
-                qkv[:, :hq * d].unflatten(1, (hq, d)), qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)),
-                qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d)), k_cache, v_cache,
-                cache_manager._cache_seqlens_buffer[:bs], cache_manager._block_table_buffer[:bs],
-                self.attention._cos_pool, self.attention._sin_pool,
-                num_splits=self._splits_for(bs, cache_manager), out=self._attn[:bs],
-                workspace=self._attn_ws)
+            attn = self._qkv_attention(normed, block, layer_idx, bs, cache_manager)
             # residual <- bf16(sum_ranks(attn @ Wo^T) + h); normed <- rmsnorm(unrounded) * ln_2
             row_parallel(attn.reshape(bs, -1), block.attn._o, h, block.ln_2, self._residual[:bs], False)
             wgemm(normed, block.mlp._gu, self._swiglu_out[:bs], swiglu=True, workspace=ws)

@@ -133,6 +133,45 @@ def paged_attn_decode(q, k_new, v_new, k_cache, v_cache, cache_seqlens, block_ta
     return out
 
 
+def paged_attn_decode_slabs(qkv_slabs, ksplit, qkv_bias, num_heads, k_cache, v_cache, cache_seqlens,
+                            block_table, rotary_cos=None, rotary_sin=None, softmax_scale=None,
+                            num_splits=0, out=None, workspace=None):
+    """`paged_attn_decode` with q | k | v read from the k-slabs the QKV projection left
+    (`wgemm_slabs`: fp32 [ksplit][B][(Hq + 2 Hkv) D] at the start of `qkv_slabs`), bias added on the
+    way in: the projection's slab-reduction launch is saved and the result is the same bit for bit."""
+    assert qkv_slabs.is_cuda and qkv_slabs.is_contiguous()
+    B = cache_seqlens.shape[0]
+    NB, page, Hkv, D = k_cache.shape
+    Hq = num_heads
+    n = (Hq + 2 * Hkv) * D
+    assert qkv_slabs.numel() * qkv_slabs.element_size() >= ksplit * B * n * 4
+    assert qkv_bias is None or (qkv_bias.dtype == torch.bfloat16 and qkv_bias.numel() == n and qkv_bias.is_contiguous())
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == v_cache.shape
+    assert cache_seqlens.dtype == torch.int32 and block_table.dtype == torch.int32
+    assert block_table.stride(1) == 1 and cache_seqlens.is_contiguous() and block_table.shape[0] == B
+    L = nv.lib()
+    if num_splits <= 0:
+        num_splits = L.mv_paged_attn_decode_pick_splits(B, Hkv, D, block_table.shape[1] * page)
+    if out is None:
+        out = torch.empty(B, Hq, D, dtype=torch.bfloat16, device=k_cache.device)
+    assert out.is_contiguous() and out.shape == (B, Hq, D)
+    if workspace is None:
+        workspace = _attn_workspace(k_cache.device, L.mv_paged_attn_decode_workspace_bytes(B, Hq, D, num_splits))
+    ws_ptr = workspace.data_ptr() if workspace is not None else None
+    ws_bytes = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    scale = float(softmax_scale) if softmax_scale is not None else float(D) ** -0.5
+    rot_max = rotary_cos.shape[0] if rotary_cos is not None else 0
+    if rotary_cos is not None:
+        assert rotary_cos.dtype == torch.bfloat16 and rotary_cos.shape[1] == D // 2
+        assert rotary_cos.is_contiguous() and rotary_sin.is_contiguous()
+    nv.check("mv_paged_attn_decode_slabs", L.mv_paged_attn_decode_slabs(
+        qkv_slabs.data_ptr(), ksplit, nv.ptr(qkv_bias), k_cache.data_ptr(), v_cache.data_ptr(),
+        nv.ptr(rotary_cos), nv.ptr(rotary_sin), rot_max, cache_seqlens.data_ptr(), block_table.data_ptr(),
+        block_table.stride(0), out.data_ptr(), ws_ptr, ws_bytes, B, Hq, Hkv, D, page, NB, scale,
+        num_splits, nv.stream_ptr()))
+    return out
+
+
 def flash_attn_with_kvcache(q, k_cache, v_cache, k=None, v=None, rotary_cos=None, rotary_sin=None,
                             cache_seqlens=None, cache_batch_idx=None, block_table=None,
                             softmax_scale=None, causal=False, window_size=(-1, -1),

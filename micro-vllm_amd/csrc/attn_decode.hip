@@ -60,7 +60,54 @@ struct AttnArgs {
     int page, page_shift, num_pages;
     float scale_log2;
     int nsplit;
+    // q, k_new, v_new as the QKV projection left them when it was cut along k: fp32 slabs
+    // [slab_ks][bs][slab_n] whose sum, in slab order, is a row of q | k | v (null: the bf16 rows above)
+    const float* slabs;
+    const uint16_t* slab_bias;   // [slab_n] or null
+    int slab_ks, slab_n;
 };
+
+// q (G heads) | k | v of row b, kv head kvh, from the projection's slabs into LDS as bf16
+// [(G + 2) * D]: what the projection's own slab reduction would have stored - the slabs added in order,
+// one rounding, then the bias and a second rounding (wgemm.hip: wgemm_finalize_kernel,
+// epilogue_value).  The workgroup shares the work, four columns a thread, every slab of a column
+// requested before the first is added: one trip to L2 for the lot.  Ends with a barrier.
+template <int D, int G>
+__device__ __forceinline__ void stage_qkv_from_slabs(const AttnArgs& a, uint16_t* stage, int b, int kvh) {
+    constexpr int NC = (G + 2) * D;
+    constexpr int kUnroll = 8;
+    const int64_t slab_stride = (int64_t)a.bs * a.slab_n;
+    for (int c = threadIdx.x * 4; c < NC; c += blockDim.x * 4) {
+        const int seg = c / D, within = c - seg * D;
+        const int head = seg < G ? kvh * G + seg : seg == G ? a.hq + kvh : a.hq + a.hkv + kvh;
+        const int col = head * D + within;
+        const float* sp = a.slabs + (int64_t)b * a.slab_n + col;
+        f32x4_t v[kUnroll];
+#pragma unroll
+        for (int ks = 0; ks < kUnroll; ++ks) {
+            if (ks >= a.slab_ks) break;   // uniform
+            v[ks] = *reinterpret_cast<const f32x4_t*>(sp + ks * slab_stride);
+        }
+        f32x4_t t = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < kUnroll; ++ks)
+            if (ks < a.slab_ks) t += v[ks];
+        for (int ks = kUnroll; ks < a.slab_ks; ++ks) t += *reinterpret_cast<const f32x4_t*>(sp + ks * slab_stride);
+        float o[4] = {round_bf16(t[0]), round_bf16(t[1]), round_bf16(t[2]), round_bf16(t[3])};
+        if (a.slab_bias) {
+            const uint2 bb = *reinterpret_cast<const uint2*>(a.slab_bias + col);
+            o[0] = round_bf16(o[0] + bf16_lo(bb.x));
+            o[1] = round_bf16(o[1] + bf16_hi(bb.x));
+            o[2] = round_bf16(o[2] + bf16_lo(bb.y));
+            o[3] = round_bf16(o[3] + bf16_hi(bb.y));
+        }
+        uint2 w;
+        w.x = pack_bf16x2(o[0], o[1]);
+        w.y = pack_bf16x2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(stage + c) = w;
+    }
+    __syncthreads();
+}
 
 // sum over the LPR adjacent lanes that hold one row; every lane gets the total
 template <int LPR>
@@ -340,13 +387,26 @@ __global__ __launch_bounds__(W * 64) void paged_attn_decode_kernel(AttnArgs a) {
     const int dpart = first_half ? d0 + D / 2 : d0 - D / 2;
     uint4 qx[G], qo[G], kx, ko, vnew;
     ko = make_uint4(0, 0, 0, 0);
+    if (a.slabs) {
+        // (the state arrays this borrows are first written after the main loop)
+        uint16_t* stage = reinterpret_cast<uint16_t*>(lds);
+        stage_qkv_from_slabs<D, G>(a, stage, b, kvh);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const uint16_t* qh = a.q + (int64_t)b * a.q_stride_b + (int64_t)(kvh * G + g) * D;
-        qx[g] = ld16(qh + d0);
-        qo[g] = rotate ? ld16(qh + dpart) : qx[g];
-    }
-    {
+        for (int g = 0; g < G; ++g) {
+            qx[g] = *reinterpret_cast<const uint4*>(stage + g * D + d0);
+            qo[g] = rotate ? *reinterpret_cast<const uint4*>(stage + g * D + dpart) : qx[g];
+        }
+        kx = *reinterpret_cast<const uint4*>(stage + G * D + d0);
+        if (rotate) ko = *reinterpret_cast<const uint4*>(stage + G * D + dpart);
+        vnew = *reinterpret_cast<const uint4*>(stage + (G + 1) * D + d0);
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const uint16_t* qh = a.q + (int64_t)b * a.q_stride_b + (int64_t)(kvh * G + g) * D;
+            qx[g] = ld16(qh + d0);
+            qo[g] = rotate ? ld16(qh + dpart) : qx[g];
+        }
         const uint16_t* kh = a.k_new + (int64_t)b * a.kv_stride_b + (int64_t)kvh * D;
         const uint16_t* vh = a.v_new + (int64_t)b * a.kv_stride_b + (int64_t)kvh * D;
         kx = ld16(kh + d0);
@@ -613,11 +673,24 @@ __global__ __launch_bounds__(256) void paged_attn_decode_mfma_kernel(AttnArgs a)
     const uint16_t* kh = a.k_new + (int64_t)b * a.kv_stride_b + (int64_t)kvh * D + q * 8;
     const uint16_t* vh = a.v_new + (int64_t)b * a.kv_stride_b + (int64_t)kvh * D + q * 8;
     uint4 qx[4], kx[4], vnew[4];
+    if (a.slabs) {
+        // (the value staging this borrows is first written in the main loop, past the barrier below)
+        uint16_t* stage = reinterpret_cast<uint16_t*>(lds);
+        stage_qkv_from_slabs<128, G>(a, stage, b, kvh);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-        qx[kk] = ld16(qh + kk * 32);
-        kx[kk] = ld16(kh + kk * 32);
-        vnew[kk] = ld16(vh + kk * 32);
+        for (int kk = 0; kk < 4; ++kk) {
+            qx[kk] = *reinterpret_cast<const uint4*>(stage + gq * 128 + q * 8 + kk * 32);
+            kx[kk] = *reinterpret_cast<const uint4*>(stage + G * 128 + q * 8 + kk * 32);
+            vnew[kk] = *reinterpret_cast<const uint4*>(stage + (G + 1) * 128 + q * 8 + kk * 32);
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            qx[kk] = ld16(qh + kk * 32);
+            kx[kk] = ld16(kh + kk * 32);
+            vnew[kk] = ld16(vh + kk * 32);
+        }
     }
 
     auto load_k = [&](uint4(&kb)[8], int pg, int c) {
@@ -1050,13 +1123,18 @@ int mv_debug_clear_attn_stamps(void) {
 }
 #endif
 
-int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, const void* v_new,
-                         int64_t kv_stride_b, void* k_cache, void* v_cache, const void* rot_cos,
-                         const void* rot_sin, int rot_max_pos, const int32_t* cache_seqlens,
-                         const int32_t* block_table, int bt_stride, void* out, void* workspace,
-                         size_t workspace_bytes, int bs, int hq, int hkv, int d, int page,
-                         int num_pages, float scale, int num_splits, mv_stream_t stream) {
-    using namespace mv;
+}  // extern "C"
+
+namespace mv {
+// The decode entry points: q / k_new / v_new as bf16 rows, or (slabs != null) as the k-slabs of the
+// QKV projection.
+static int decode_entry(const void* q, int64_t q_stride_b, const void* k_new, const void* v_new,
+                        int64_t kv_stride_b, const float* slabs, int slab_ks, const void* slab_bias,
+                        void* k_cache, void* v_cache, const void* rot_cos, const void* rot_sin,
+                        int rot_max_pos, const int32_t* cache_seqlens, const int32_t* block_table,
+                        int bt_stride, void* out, void* workspace, size_t workspace_bytes, int bs, int hq,
+                        int hkv, int d, int page, int num_pages, float scale, int num_splits,
+                        mv_stream_t stream) {
     if (!q || !k_new || !v_new || !k_cache || !v_cache || !cache_seqlens || !block_table || !out)
         return MV_ERR_INVALID_ARG;
     if (bs <= 0 || hq <= 0 || hkv <= 0 || page <= 0 || num_pages <= 0 || bt_stride <= 0 ||
@@ -1108,9 +1186,43 @@ int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, c
     if (num_splits > 1 && num_splits <= 128 && g_tune_inkernel_merge.load(std::memory_order_relaxed) &&
         bs * hkv <= kMaxArrive)
         a.arrive = (unsigned int*)workspace;
+    a.slabs = slabs;
+    a.slab_ks = slab_ks;
+    a.slab_n = (hq + 2 * hkv) * d;
+    a.slab_bias = (const uint16_t*)slab_bias;
     const int g = hq / hkv;
     hipStream_t s = (hipStream_t)stream;
     return d == 128 ? dispatch_g<128>(a, g, s) : dispatch_g<64>(a, g, s);
+}
+}  // namespace mv
+
+extern "C" {
+
+int mv_paged_attn_decode(const void* q, int64_t q_stride_b, const void* k_new, const void* v_new,
+                         int64_t kv_stride_b, void* k_cache, void* v_cache, const void* rot_cos,
+                         const void* rot_sin, int rot_max_pos, const int32_t* cache_seqlens,
+                         const int32_t* block_table, int bt_stride, void* out, void* workspace,
+                         size_t workspace_bytes, int bs, int hq, int hkv, int d, int page,
+                         int num_pages, float scale, int num_splits, mv_stream_t stream) {
+    return mv::decode_entry(q, q_stride_b, k_new, v_new, kv_stride_b, nullptr, 0, nullptr, k_cache, v_cache,
+                            rot_cos, rot_sin, rot_max_pos, cache_seqlens, block_table, bt_stride, out,
+                            workspace, workspace_bytes, bs, hq, hkv, d, page, num_pages, scale, num_splits,
+                            stream);
+}
+
+int mv_paged_attn_decode_slabs(const void* qkv_slabs, int ksplit, const void* qkv_bias, void* k_cache,
+                               void* v_cache, const void* rot_cos, const void* rot_sin, int rot_max_pos,
+                               const int32_t* cache_seqlens, const int32_t* block_table, int bt_stride,
+                               void* out, void* workspace, size_t workspace_bytes, int bs, int hq, int hkv,
+                               int d, int page, int num_pages, float scale, int num_splits,
+                               mv_stream_t stream) {
+    if (!qkv_slabs || ksplit < 1 || ksplit > 64 || !mv::aligned16(qkv_slabs)) return MV_ERR_INVALID_ARG;
+    if (qkv_bias && !mv::aligned16(qkv_bias)) return MV_ERR_INVALID_ARG;
+    // (the row pointers are not read in this mode; they only have to pass the checks)
+    return mv::decode_entry(qkv_slabs, 0, qkv_slabs, qkv_slabs, 0, (const float*)qkv_slabs, ksplit, qkv_bias,
+                            k_cache, v_cache, rot_cos, rot_sin, rot_max_pos, cache_seqlens, block_table,
+                            bt_stride, out, workspace, workspace_bytes, bs, hq, hkv, d, page, num_pages,
+                            scale, num_splits, stream);
 }
 
 }  // extern "C"

@@ -354,3 +354,78 @@ def test_calls_on_two_streams_do_not_share_state(mv):
         for o in outs[i]:
             assert torch.equal(o, alone[i])
         check_output(outs[i][0], cases[i], what=f"stream {i}")
+
+
+def _slab_case(B, Hq, Hkv, D, hidden, bias, seed):
+    """A QKV projection of B rows and the cache state it feeds: returns what both routes need."""
+    from micro_vllm_amd.kernel.linear import StreamedWeight
+
+    g = torch.Generator().manual_seed(seed)
+    ctxs = [int(c) for c in torch.randint(0, 900, (B,), generator=g)]
+    ctxs[0], ctxs[-1] = 0, 256
+    case = make_case(B, Hq, Hkv, D, 256, ctxs, seed=seed + 1)
+    n = (Hq + 2 * Hkv) * D
+    x = torch.randn(B, hidden, generator=g).to(torch.bfloat16).to(DEV)
+    w = StreamedWeight.from_linear((torch.randn(n, hidden, generator=g) * 0.05).to(torch.bfloat16).to(DEV))
+    b = (torch.randn(n, generator=g) * 0.5).to(torch.bfloat16).to(DEV) if bias else None
+    return case, x, w, b
+
+
+@pytest.mark.parametrize("B,Hq,Hkv,D,hidden,bias,force_mfma", [
+    (32, 8, 2, 128, 1024, False, False), (32, 8, 2, 128, 1024, True, True), (8, 8, 1, 128, 2048, True, False),
+    (17, 8, 2, 64, 512, True, False), (5, 7, 1, 64, 448, True, False), (32, 32, 8, 128, 4096, False, False)])
+def test_attention_fed_from_projection_slabs_equals_the_two_step_route(mv, B, Hq, Hkv, D, hidden, bias, force_mfma):
+    """q | k | v summed from the QKV projection's k-slabs inside the attention kernel, bias included:
+    the output and the cache rows it appends are the bits the projection's own slab reduction
+    followed by the plain attention call produce."""
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.core.paged_attention import paged_attn_decode, paged_attn_decode_slabs
+    from micro_vllm_amd.kernel.linear import wgemm, wgemm_slabs
+
+    L = nv.lib()
+    case, x, w, b = _slab_case(B, Hq, Hkv, D, hidden, bias, seed=B + Hq + D)
+    if force_mfma:
+        assert L.mv_paged_attn_tune(2, 2) == 0
+    try:
+        to = lambda t: t.to(DEV)
+        n = (Hq + 2 * Hkv) * D
+        ws = torch.zeros(L.mv_wgemm_postnorm_workspace_bytes(B, n, hidden) // 4 + 64, dtype=torch.float32, device=DEV)
+        outs = []
+        for route in ("two steps", "slabs"):
+            kc, vc = to(case["k_cache"]), to(case["v_cache"])
+            for splits in (1, 3):
+                kc.copy_(case["k_cache"]); vc.copy_(case["v_cache"])
+                if route == "slabs":
+                    ks = wgemm_slabs(x, w, ws)
+                    assert ks == L.mv_wgemm_slab_count(B, n, hidden) >= 1
+                    out = paged_attn_decode_slabs(ws, ks, b, Hq, kc, vc, to(case["seqlens"]), to(case["bt"]),
+                                                  to(case["cos"]), to(case["sin"]), num_splits=splits)
+                else:
+                    qkv = wgemm(x, w, torch.empty(B, n, dtype=torch.bfloat16, device=DEV), bias=b, workspace=ws,
+                                plan_slabs=True)
+                    out = paged_attn_decode(
+                        qkv[:, :Hq * D].unflatten(1, (Hq, D)), qkv[:, Hq * D:(Hq + Hkv) * D].unflatten(1, (Hkv, D)),
+                        qkv[:, (Hq + Hkv) * D:].unflatten(1, (Hkv, D)), kc, vc, to(case["seqlens"]), to(case["bt"]),
+                        to(case["cos"]), to(case["sin"]), num_splits=splits)
+                outs.append((route, splits, out.clone(), kc.clone(), vc.clone()))
+        for splits in (1, 3):
+            a = next(o for o in outs if o[0] == "two steps" and o[1] == splits)
+            s = next(o for o in outs if o[0] == "slabs" and o[1] == splits)
+            assert torch.equal(a[2], s[2]), f"output differs at {splits} split(s)"
+            assert torch.equal(a[3], s[3]) and torch.equal(a[4], s[4]), "appended cache rows differ"
+    finally:
+        if force_mfma:
+            assert L.mv_paged_attn_tune(2, 0) == 0
+
+
+def test_slab_entry_point_rejects_bad_arguments(mv):
+    from micro_vllm_amd import _native as nv
+
+    L = nv.lib()
+    t = torch.zeros(4096, dtype=torch.float32, device=DEV)
+    i = torch.zeros(64, dtype=torch.int32, device=DEV)
+    args = lambda slabs, ks: (slabs, ks, None, t.data_ptr(), t.data_ptr(), None, None, 0, i.data_ptr(), i.data_ptr(), 4,
+                              t.data_ptr(), None, 0, 1, 2, 1, 64, 16, 1, 0.125, 1, None)
+    assert L.mv_paged_attn_decode_slabs(*args(None, 1)) == nv.MV_ERR_INVALID_ARG
+    assert L.mv_paged_attn_decode_slabs(*args(t.data_ptr(), 0)) == nv.MV_ERR_INVALID_ARG
+    assert L.mv_paged_attn_decode_slabs(*args(t.data_ptr() + 4, 1)) == nv.MV_ERR_INVALID_ARG

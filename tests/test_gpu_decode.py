@@ -223,15 +223,18 @@ def test_duplicate_padded_batch(mv):
     assert torch.equal(got[0], got[3])
 
 
-@pytest.mark.parametrize("bs", [5, 8])
-def test_batched_path_with_norms_on_the_slab_reduction_equals_the_per_kernel_path(mv, bs):
-    """bs > 4: the decode step whose O and down projections carry the following norm
-    (`_decode_batched`) against the same step built from `_layer` + `_head` (separate norm
-    kernels): same logits, bit for bit, and the same KV written."""
+@pytest.mark.parametrize("bs,shape,bias", [(5, "tiny-gqa", False), (8, "tiny-gqa", False), (8, "tiny-mha", True),
+                                           (7, "tiny-gqa7", True), (8, "tiny-d128", False)])
+def test_batched_path_with_norms_on_the_slab_reduction_equals_the_per_kernel_path(mv, bs, shape, bias):
+    """bs > 4: the decode step whose O and down projections carry the following norm and whose
+    attention adds up the QKV projection's slabs, bias included (`_decode_batched`), against the same
+    step built from `_layer` + `_head` (separate norm kernels, QKV rows stored by the projection):
+    same logits, bit for bit, and the same KV written."""
     from micro_vllm_amd.kernel.linear import embedding
 
-    cfg, r1, m1, _, rc1 = build(mv, "tiny-gqa", n_blocks=40)
-    _, r2, m2, _, rc2 = build(mv, "tiny-gqa", n_blocks=40)
+    cfg, r1, m1, _, rc1 = build(mv, shape, qkv_bias=bias, n_blocks=40)
+    _, r2, m2, _, rc2 = build(mv, shape, qkv_bias=bias, n_blocks=40)
+    assert r1.qkv_slabs
     seq_lens = [3, 250, 257, 31, 64, 500, 9, 129][:bs]
     prefill_random_kv(m1, rc1, seq_lens, seed=7)
     prefill_random_kv(m2, rc2, seq_lens, seed=7)
