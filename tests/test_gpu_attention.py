@@ -429,3 +429,38 @@ def test_slab_entry_point_rejects_bad_arguments(mv):
     assert L.mv_paged_attn_decode_slabs(*args(None, 1)) == nv.MV_ERR_INVALID_ARG
     assert L.mv_paged_attn_decode_slabs(*args(t.data_ptr(), 0)) == nv.MV_ERR_INVALID_ARG
     assert L.mv_paged_attn_decode_slabs(*args(t.data_ptr() + 4, 1)) == nv.MV_ERR_INVALID_ARG
+
+
+@pytest.mark.parametrize("ks", [1, 3, 8, 11])
+def test_slab_sums_of_any_count_follow_the_slab_order(mv, ks):
+    """Slab counts up to and past the eight the kernel requests ahead: q | k | v must be the slabs
+    added in order (fp32), one rounding, the bias, a second rounding - formed here with tensor
+    operations and fed to the plain entry point."""
+    from micro_vllm_amd.core.paged_attention import paged_attn_decode, paged_attn_decode_slabs
+
+    B, Hq, Hkv, D = 6, 8, 2, 128
+    n = (Hq + 2 * Hkv) * D
+    g = torch.Generator().manual_seed(100 + ks)
+    case = make_case(B, Hq, Hkv, D, 256, [0, 5, 255, 256, 300, 1000], seed=ks)
+    # slabs of very different magnitudes, so that the order of the additions matters
+    slabs = torch.randn(ks, B, n, generator=g) * torch.logspace(-3, 1, ks).reshape(ks, 1, 1)
+    bias = (torch.randn(n, generator=g) * 0.5).to(torch.bfloat16)
+    acc = torch.zeros(B, n)
+    for s in range(ks):
+        acc = acc + slabs[s]
+    qkv = (acc.to(torch.bfloat16).float() + bias.float()).to(torch.bfloat16).to(DEV)
+    to = lambda t: t.to(DEV)
+    outs = []
+    for route in (0, 1):
+        kc, vc = to(case["k_cache"]), to(case["v_cache"])
+        if route == 0:
+            out = paged_attn_decode(
+                qkv[:, :Hq * D].unflatten(1, (Hq, D)), qkv[:, Hq * D:(Hq + Hkv) * D].unflatten(1, (Hkv, D)),
+                qkv[:, (Hq + Hkv) * D:].unflatten(1, (Hkv, D)), kc, vc, to(case["seqlens"]), to(case["bt"]),
+                to(case["cos"]), to(case["sin"]), num_splits=2)
+        else:
+            out = paged_attn_decode_slabs(to(slabs).contiguous(), ks, to(bias), Hq, kc, vc, to(case["seqlens"]),
+                                          to(case["bt"]), to(case["cos"]), to(case["sin"]), num_splits=2)
+        outs.append((out.clone(), kc, vc))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
