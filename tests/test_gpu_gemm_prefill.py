@@ -76,12 +76,14 @@ def _cus():
 
 # tile width the planner gives each case on a 256-CU device: form 1 = 256 columns, 2 = 192, 3 = 224
 WIDE_FORM = {(1000, 8208): 2, (2300, 4096): 2, (1300, 6144): 2, (1025, 8192): 2, (2048, 4096): 2,
-             (700, 22016): 2, (2048, 28672): 3, (2048, 8192): 1}
+             (700, 22016): 2, (2048, 28672): 3, (2048, 8192): 1, (2000, 7120): 3}
 
 
 @pytest.mark.parametrize("m,n,k,mode", [(1000, 8208, 256, "plain"), (2300, 4096, 512, "residual"),
                                         (1300, 6144, 512, "bias"), (2048, 28672, 256, "swiglu"),
                                         (2048, 8192, 256, "plain"),
+                                        # 224-column tiles, the last one 11 strips wide, the last m-block ragged
+                                        (2000, 7120, 256, "residual"),
                                         (1025, 8192, 320, "bias"), (2048, 4096, 1024, "f32"),
                                         (700, 22016, 256, "swiglu"), (4096, 2048, 4096, "plain"),
                                         # tiles for half the CUs and a long k: two k-slices of the wide form
