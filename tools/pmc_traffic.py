@@ -40,6 +40,13 @@ def main():
     d[key + ":detail"] = {"launches": nf, "fetch_bytes_per_launch": int(fetch_b),
                           "write_bytes_per_launch": int(write_b),
                           "note": "FETCH_SIZE KiB x 1024 x 2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE KiB x 1024"}
+    if "paged_attn" in kernel:
+        # the counter is calibrated for wide coalesced streams only; this kernel reads 256-byte rows
+        # (16 lanes x 16 B) at a 2 KiB stride, every row exactly once
+        d[key + ":detail"]["note"] += ("; UNCALIBRATED for this kernel's access width (256-byte row segments): the "
+                                       "figure is below the bytes the kernel must read (every cached row once: "
+                                       "(ctx + 1) x 2 x D x 2 bytes per sequence and kv head), so it is kept as a "
+                                       "ratio between variants only")
     if source:
         d[key + ":detail"]["source"] = source
     json.dump(d, open(out, "w"), indent=1, sort_keys=True)
