@@ -2,8 +2,15 @@
 Llama-shaped model, with the HBM roofline of the dominant kernel and the CPU restatement of
 the reference path timed beside it.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1: one process)
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (tensor parallel)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+With --gpus N > 1 the model is cut over N tensor-parallel ranks, one process per GPU.  Started
+under a launcher (WORLD_SIZE set) the process is one of those ranks; started plainly it becomes
+the launcher itself: it starts N fresh rank processes of this file (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment), passes rank 0's JSON line through,
+ends every rank when one fails, and never touches a GPU itself.  More ranks than GPUs is refused
+unless MVLLM_SHARE_GPU=1 (a rehearsal of the several-ranks path on one card).
 
 A step = one token for every sequence of the batch: KVCacheManager.append + cache_batch_data
 (host), hipGraph replay of the whole N-layer forward (device), greedy argmax on the device
@@ -190,9 +197,34 @@ def projection_timing(runner, bs, layers, reps=20):
             h_in = runner._mlp_out[:bs]
         return layers + 1
 
+    def tp_pass():          # ModelGraphRunner._decode_tp without its attention and reduction launches
+        slabs = getattr(runner._reducer, "takes_slabs", False)
+        for li in range(layers):
+            b = tr.h[li]
+            if bs > 4 and runner.qkv_slabs:
+                wgemm_slabs(normed, b.attn._qkv_w, ws)
+            else:
+                wgemm(normed, b.attn._qkv_w, runner._qkv[:bs], bias=b.attn._qkv_b, workspace=ws, plan_slabs=bs > 4)
+            if slabs:
+                wgemm_slabs(attn, b.attn._o, ws)
+            else:
+                wgemm(attn, b.attn._o, runner._attn_out[:bs], workspace=ws)
+            wgemm(normed, b.mlp._gu, runner._swiglu_out[:bs], swiglu=True, workspace=ws)
+            if slabs:
+                wgemm_slabs(runner._swiglu_out[:bs], b.mlp._d, ws)
+            else:
+                wgemm(runner._swiglu_out[:bs], b.mlp._d, runner._attn_out[:bs], workspace=ws)
+        if getattr(runner, "_gatherer", None) is not None:   # head cut by vocabulary rows
+            wgemm(normed, runner._lm_head_shard, runner._logits_local[:bs], workspace=ws)
+        else:
+            wgemm(normed, runner._lm_head, runner._logits[:bs], workspace=ws)
+        return 4 * layers + 1
+
     def one_pass():
         if chained:
             return chained_pass()
+        if runner.world_size > 1:
+            return tp_pass()
         n = 0
         for li in range(layers):
             b = tr.h[li]
@@ -273,8 +305,11 @@ def roofline_block(runner, cfg, bs, layers, world, weight_bytes, step_bytes, ste
         "bytes_per_launch": int(per_launch),
         "avg_launch_us": round(t_k * 1e6, 3),
         "launches_per_step": n_launch,
-        "timing": "HIP events around a hipGraph of the step's projection launches as the step issues them "
-                  "(norm prologues / slab-reduction norms and epilogues included), measured in this run",
+        "timing": ("HIP events around a hipGraph of this rank's projection launches as the several-ranks step "
+                   "issues them (k-slabs left for the reductions; the reduction + add + norm launches and "
+                   "attention are not in it), measured in this run" if world > 1 else
+                   "HIP events around a hipGraph of the step's projection launches as the step issues them "
+                   "(norm prologues / slab-reduction norms and epilogues included), measured in this run"),
         "step_frac": round(step_bytes / step_seconds / 1e9 / HBM_PEAK_GBS, 4),
     }
 
@@ -507,13 +542,89 @@ def cpu_baseline(args, cfg, runner, dev):
     }
 
 
+def launch_ranks(args) -> int:
+    """The parent of a several-GPU run started without a launcher: N child processes of this file,
+    one per rank, as the reference is started (one process per GPU from RANK / WORLD_SIZE,
+    core/parallel_config.py:21-32).  Nothing here initialises a GPU (counting devices does not),
+    and the children are fresh processes, not re-executions of this one.  Rank 0's standard output
+    (the JSON line) is passed through; everything else the ranks print goes to standard error.
+    Returns the exit code: 0 only if every rank ended with 0; the first failure ends the others."""
+    import socket
+    import subprocess
+    import threading
+
+    n = args.gpus
+    ndev = torch.cuda.device_count()
+    share = os.environ.get("MVLLM_SHARE_GPU", "0") == "1"
+    if ndev < 1:
+        log("bench.py needs a GPU (the HIP path has no fallback)")
+        return 2
+    if n > ndev and not share:
+        log(f"--gpus {n} but only {ndev} GPU(s) are visible; set MVLLM_SHARE_GPU=1 to rehearse "
+            f"{n} ranks on fewer cards (no measure of scaling)")
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs, lines = [], []
+
+    def pump(stream):
+        for line in stream:
+            lines.append(line)
+
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r % ndev), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        if n > ndev:
+            # RCCL refuses two ranks on one device: the rehearsal meets over gloo; the data path's
+            # own exchange (mapped peer buffers) is the same either way
+            env.setdefault("MVLLM_DIST_BACKEND", "gloo")
+        procs.append(subprocess.Popen([sys.executable, "-u", os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    reader = threading.Thread(target=pump, args=(procs[0].stdout,), daemon=True)
+    reader.start()
+    deadline = time.time() + float(os.environ.get("MVLLM_BENCH_LAUNCH_TIMEOUT_S", "1700"))
+    code = 0
+    while True:
+        states = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(states) if c not in (None, 0)]
+        if bad:
+            code = bad[0][1] if bad[0][1] > 0 else 1
+            log(f"[bench] rank {bad[0][0]} ended with {bad[0][1]}; ending the other ranks")
+            break
+        if all(c == 0 for c in states):
+            break
+        if time.time() > deadline:
+            log("[bench] the ranks did not finish in time; ending them")
+            code = 124
+            break
+        time.sleep(0.2)
+    if code:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5)
+    sys.stdout.write("".join(lines))
+    sys.stdout.flush()
+    return code
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.as_rank_of:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and args.gpus > 1:
-        log(f"--gpus {args.gpus} needs the torch.distributed.run launcher; running 1 GPU")
+    if world != max(1, args.gpus) and not args.as_rank_of:
+        log(f"[bench] --gpus {args.gpus} under a launcher of {world} rank(s): running {world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
     local %= torch.cuda.device_count()  # rehearsals put several ranks on one GPU (gloo backend)
     torch.cuda.set_device(local)

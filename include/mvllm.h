@@ -3,9 +3,13 @@
  *
  * Every entry point is a plain C function: raw device pointers, sizes and
  * strides in ELEMENTS, an explicit hipStream_t (passed as void*), and an int
- * return code (0 = ok, negative = mv_status below).  Nothing here allocates,
- * frees or synchronises: the caller owns every buffer, and all launches are
- * legal under HIP stream capture.  The entry points keep no state on the device
+ * return code (0 = ok, negative = mv_status below).  No STEP call (anything that
+ * takes a stream) allocates, frees or synchronises: the caller owns every buffer,
+ * and all launches are legal under HIP stream capture.  The set-up and tear-down
+ * calls of the communicators (mv_allreduce_init / _connect / _destroy,
+ * mv_allgather_init) do allocate, map and free device memory and wait for the
+ * device; mv_decode_chain_status copies a word back and waits for it.  They say
+ * so where they are declared.  The entry points keep no state on the device
  * between calls except in the buffers the caller passes, so calls on different
  * streams (or threads) are independent as long as they are given different
  * workspaces; the one exception is mv_paged_attn_decode_noalloc, which says so.  All tensors are bf16 unless a parameter
@@ -397,7 +401,11 @@ int mv_sample_or_greedy(const void* logits, int64_t ld, int rows, int n, const f
  * epoch kept in device memory that only grows, so a captured step can be replayed.  All ranks must
  * issue the same sequence of calls with the same `rows`.  A rank that waits longer than
  * MVLLM_ALLREDUCE_TIMEOUT_MS (default 10 s) for a peer gives up, finishes with a wrong sum and sets
- * the status word mv_allreduce_status reads (0 = no timeout so far; synchronising call). */
+ * the communicator's status word (1 + the rank that did not arrive; 0 = no timeout so far).  The word
+ * is host memory mapped into the device: mv_allreduce_status is a plain load that neither waits nor
+ * touches the device, and tells about the step calls the caller has already waited for (so a serving
+ * loop reads it right after the token read-back of a step, before it uses the tokens).  After a
+ * timeout the ranks' epochs may be out of step: destroy the communicator, do not go on with it. */
 size_t mv_allreduce_handle_bytes(void);
 int mv_allreduce_init(int rank, int world, int max_rows, int max_n, void** comm_out);
 int mv_allreduce_get_handle(void* comm, void* handle_out);

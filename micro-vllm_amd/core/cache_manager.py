@@ -66,6 +66,7 @@ class KVCacheManager:
         self._free = collections.deque(range(n_blocks))
         self._blocks = {}  # seq_id -> [block ids]
         self._pos = {}     # block id -> used slots
+        self._opened_by_append = {}   # seq_id -> whether its latest append took a page from the free list
 
         self.cache_seqlens = torch.tensor([1], dtype=torch.int32, device=self.device)
         self.max_tokens = max_tokens
@@ -125,11 +126,13 @@ class KVCacheManager:
         used = self._pos[last]
         if used < self.block_size - 1:
             self._pos[last] = used + 1
+            self._opened_by_append[seq_id] = False
             return last * self.block_size + used
         if self._free:
             nb = self._free.popleft()
             blocks.append(nb)
             self._pos[nb] = 1
+            self._opened_by_append[seq_id] = True
             return nb * self.block_size
         print(f"cache_manager.append failed for seq {seq_id}: no free block "
               f"(blocks={blocks}, used={used}, block_size={self.block_size})")
@@ -138,13 +141,17 @@ class KVCacheManager:
     def unappend(self, seq_id: int, slot: int):
         """Take back the `append` that returned `slot` (the step it was made for will not run):
         a page opened by it goes back to the head of the free list, otherwise the page's fill
-        count drops by one."""
+        count drops by one.  Whether the append opened a page is what it recorded, not what the
+        slot number suggests: offset 0 of an EXISTING page is also what the first append after a
+        prompt of a whole number of pages returns under `strict_reference` (that page holds
+        prompt rows and must stay)."""
         blocks = self._blocks.get(seq_id)
         if not blocks or slot < 0:
             return
         last = blocks[-1]
         assert slot // self.block_size == last, "not this sequence's latest slot"
-        if slot % self.block_size == 0 and self._pos.get(last) == 1 and len(blocks) > 1:
+        if self._opened_by_append.pop(seq_id, False):
+            assert slot % self.block_size == 0 and self._pos.get(last) == 1 and len(blocks) > 1
             blocks.pop()
             self._pos.pop(last, None)
             self._free.appendleft(last)
@@ -235,6 +242,7 @@ class KVCacheManager:
 
     def free(self, seq_id: int):
         blocks = self._blocks.pop(seq_id, None)
+        self._opened_by_append.pop(seq_id, None)
         if blocks:
             for b in blocks:
                 self._free.append(b)
@@ -244,6 +252,7 @@ class KVCacheManager:
         self._free = collections.deque(range(self.n_blocks))
         self._blocks.clear()
         self._pos.clear()
+        self._opened_by_append.clear()
 
     @property
     def stats(self):

@@ -24,8 +24,6 @@ from .sequence import Sequence
 logger = logging.getLogger("InferenceEngine")
 
 
-@dataclass
-
 class KVPoolExhausted(RuntimeError):
     """A decode step could not get a KV slot for `seq_ids`; nothing of the step was run and the other
     sequences of the batch are as they were before it."""
@@ -34,6 +32,8 @@ class KVPoolExhausted(RuntimeError):
         super().__init__("OOM: no free KV page for sequence(s) %s" % ", ".join(str(i) for i in seq_ids))
         self.seq_ids = list(seq_ids)
 
+
+@dataclass
 class InferenceStats:
     prep_time: float = 0.0
     gpu_time: float = 0.0
@@ -321,8 +321,16 @@ class InferenceEngine:
                 temps = torch.tensor([t for t, _ in key], device=device)
                 topp = torch.tensor([p for _, p in key], device=device)
                 next_tokens = self._sample(logits, temps, topp, 50)
+            # the read-back above waited for the step: a reduction or gather of it that gave up on a
+            # peer has set its communicator's (host-visible) status word by now, and the tokens are
+            # thrown away before anybody sees them
+            self.graph_runner.raise_if_exchange_failed()
             for i, seq in enumerate(batch):
                 seq._next_token = next_tokens[i]
+        else:
+            # no read-back on this rank: the word speaks for the steps that have finished so far,
+            # so a failed exchange is noticed a step late at worst
+            self.graph_runner.raise_if_exchange_failed()
 
     def update_sequences(self, sequences: List[Sequence]):
         """core/engine.py:287-309: apply each sequence's sampled token once, stream it, retire

@@ -582,6 +582,17 @@ class ModelGraphRunner:
             return self._gatherer.gather(self._logits_local[:bs], self._logits[:bs])
         return wgemm(normed, self._lm_head, self._logits[:bs], workspace=ws)
 
+    def raise_if_exchange_failed(self):
+        """Raises kernel.allreduce.ExchangeTimeout if a reduction or logits gather of a finished
+        step gave up waiting for a peer (its results are wrong).  A read of two host words: call it
+        after waiting for the step, e.g. behind the read-back of its tokens."""
+        if self.world_size > 1:
+            for comm, what in ((self._reducer, "all-reduce of a decode step"),
+                               (self._gatherer, "logits all-gather of a decode step")):
+                check = getattr(comm, "raise_if_timed_out", None)
+                if check is not None:
+                    check(what)
+
     def greedy_ids(self, logits: torch.Tensor):
         """Row-wise argmax of `logits` if they are what the last decode returned (then it is already
         there), else None."""

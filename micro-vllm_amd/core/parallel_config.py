@@ -12,6 +12,7 @@ class _State:
     group = None
     reducer = None
     gatherer = None
+    retired = []    # communicators replaced by larger ones: runners built earlier may still hold them
 
 
 _st = _State()
@@ -80,7 +81,10 @@ def tensor_parallel_reducer(max_rows: int, max_n: int):
     """The object that sums the decode step's [bs, hidden] partials over the ranks and applies the
     add + RMSNorm that follows (kernel/allreduce.py).  With every rank on a GPU of one node this is
     the one-shot all-reduce over mapped peer buffers, unless MVLLM_ALLREDUCE=dist asks for
-    torch.distributed; whichever is chosen, all ranks choose the same (they vote).  One per process."""
+    torch.distributed; whichever is chosen, all ranks choose the same (they vote).  One per process,
+    sized for the library's row limit whatever the first caller asks for, so that a second runner
+    with a larger batch shares it; one that is outgrown all the same (a wider hidden size) stays
+    alive for the runners and captured graphs that hold it and a larger one is made beside it."""
     from ..kernel.allreduce import MAX_N, MAX_ROWS, DistAllReduce, IpcAllReduce
 
     world = get_world_size()
@@ -89,10 +93,10 @@ def tensor_parallel_reducer(max_rows: int, max_n: int):
     if red is not None and red.fits(max_rows, max_n):
         return red
     if red is not None:
-        red.close()
+        _st.retired.append(red)
     want_ipc = (os.environ.get("MVLLM_ALLREDUCE", "ipc") != "dist" and torch.cuda.is_available()
                 and world <= 8 and max_rows <= MAX_ROWS and max_n <= MAX_N and max_n % 8 == 0)
-    comm = _agree_on_ipc_comm(lambda: IpcAllReduce(get_rank(), world, max_rows, max_n), want_ipc,
+    comm = _agree_on_ipc_comm(lambda: IpcAllReduce(get_rank(), world, MAX_ROWS, max_n), want_ipc,
                               "one-shot all-reduce")
     _st.reducer = comm if comm is not None else DistAllReduce(all_reduce)
     return _st.reducer
@@ -155,9 +159,9 @@ def tensor_parallel_gatherer(max_rows: int, n_local: int):
     if g is not None and g.max_rows >= max_rows and g.max_n == n_local:
         return g
     if g is not None:
-        g.close()
+        _st.retired.append(g)   # never closed under a runner that may still hold it
     want = (os.environ.get("MVLLM_LM_HEAD_SHARD", "1") != "0" and max_rows <= MAX_ROWS and n_local % 8 == 0)
-    _st.gatherer = _agree_on_ipc_comm(lambda: IpcAllGather(get_rank(), world, max_rows, n_local), want,
+    _st.gatherer = _agree_on_ipc_comm(lambda: IpcAllGather(get_rank(), world, MAX_ROWS, n_local), want,
                                       "logits all-gather")
     return _st.gatherer
 

@@ -22,6 +22,9 @@
 // All ranks must issue the same sequence of calls with the same row counts (tensor parallelism
 // does).  A peer that never arrives is given up on after a timeout: the kernel sets the
 // communicator's status word and finishes (with a wrong sum), so a dead rank cannot hang the GPU.
+// The status word lives in host memory mapped into the device (written with a system-scope store), so
+// the host reads it with a plain load right after the wait it already does for the step's tokens -
+// no extra synchronisation - and turns it into an error before the tokens are used.
 #include "common.h"
 
 #include <stdlib.h>
@@ -42,7 +45,7 @@ struct ArArgs {
     int rank, world;
     int max_rows, max_n;                // capacity the buffers were sized for
     unsigned int* epoch;                // [kArMaxRows] this rank's per-row epoch (plain device memory)
-    int* status;                        // set non-zero when a wait timed out
+    int* status;                        // host-mapped word, set non-zero when a wait timed out
     unsigned long long timeout_ticks;   // of the constant 100 MHz counter
     // this rank's partial: bf16 rows, or fp32 k-slabs [ksplit][rows][n] of the projection that made it
     const uint16_t* in;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(kArThreads) void allreduce_addnorm_kernel(ArArgs a)
             const unsigned int v = __hip_atomic_load(mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((int)(v - e) >= 0) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
-                __hip_atomic_store(a.status, 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.status, 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(kAgThreads) void allgather_kernel(AgArgs a) {
             const unsigned int v = __hip_atomic_load(mf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if ((int)(v - e) >= 0) break;
             if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
-                __hip_atomic_store(a.status, 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.status, 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -345,7 +348,8 @@ struct ArComm {
     bool opened[kArMaxWorld] = {};
     hipIpcMemHandle_t handle;
     unsigned int* epoch = nullptr;
-    int* status = nullptr;
+    int* status = nullptr;        // device address of the status word
+    int* status_host = nullptr;   // the same word as the host sees it (pinned, mapped, coherent)
     unsigned long long timeout_ticks = 0;
     bool connected = false;
     bool fences = false;   // MVLLM_ALLREDUCE_FENCES=1
@@ -403,25 +407,28 @@ static int comm_init(int rank, int world, int max_rows, int max_n, bool gather, 
     if (e != hipSuccess) { delete c; return ar_fail(e); }
     c->local = (unsigned char*)p;
     c->peers[rank] = c->local;
-    void *ep = nullptr, *sp = nullptr;
+    void *ep = nullptr, *sp = nullptr, *sp_dev = nullptr;
     if ((e = hipMalloc(&ep, kArMaxRows * sizeof(unsigned int))) != hipSuccess ||
-        (e = hipMalloc(&sp, 256)) != hipSuccess ||
+        (e = hipHostMalloc(&sp, 256, hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess ||
+        (e = hipHostGetDevicePointer(&sp_dev, sp, 0)) != hipSuccess ||
         (e = hipMemset(c->local, 0, c->bytes)) != hipSuccess ||
         (e = hipMemset(ep, 0, kArMaxRows * sizeof(unsigned int))) != hipSuccess ||
-        (e = hipMemset(sp, 0, 256)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) {
+        (e = hipDeviceSynchronize()) != hipSuccess) {
         if (ep) (void)hipFree(ep);
-        if (sp) (void)hipFree(sp);
+        if (sp) (void)hipHostFree(sp);
         (void)hipFree(c->local);
         delete c;
         return ar_fail(e);
     }
+    memset(sp, 0, 256);
     c->epoch = (unsigned int*)ep;
-    c->status = (int*)sp;
+    c->status_host = (int*)sp;
+    c->status = (int*)sp_dev;
     memset(&c->handle, 0, sizeof(c->handle));
     if (world > 1) {
         e = hipIpcGetMemHandle(&c->handle, c->local);
         if (e != hipSuccess) {
-            (void)hipFree(ep); (void)hipFree(sp); (void)hipFree(c->local);
+            (void)hipFree(ep); (void)hipHostFree(sp); (void)hipFree(c->local);
             delete c;
             return ar_fail(e);
         }
@@ -471,8 +478,9 @@ int mv_allreduce_set_timeout_ms(void* comm, double ms) {
 
 int mv_allreduce_status(void* comm, int* status_out) {
     if (!comm || !status_out) return MV_ERR_INVALID_ARG;
-    hipError_t e = hipMemcpy(status_out, ((mv::ArComm*)comm)->status, sizeof(int), hipMemcpyDeviceToHost);
-    return e == hipSuccess ? MV_OK : mv::ar_fail(e);
+    // a plain load of host memory: it tells about the step calls the caller has already waited for
+    *status_out = *(volatile int*)((mv::ArComm*)comm)->status_host;
+    return MV_OK;
 }
 
 int mv_allreduce_destroy(void* comm) {
@@ -483,7 +491,7 @@ int mv_allreduce_destroy(void* comm) {
     for (int p = 0; p < c->world; ++p)
         if (c->opened[p]) (void)hipIpcCloseMemHandle(c->peers[p]);
     if (c->epoch) (void)hipFree(c->epoch);
-    if (c->status) (void)hipFree(c->status);
+    if (c->status_host) (void)hipHostFree(c->status_host);
     if (c->local) (void)hipFree(c->local);
     delete c;
     return MV_OK;

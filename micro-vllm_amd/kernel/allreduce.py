@@ -28,6 +28,17 @@ MAX_ROWS = 64
 MAX_N = 8192
 
 
+class ExchangeTimeout(RuntimeError):
+    """A rank waited longer than the communicator's timeout for a peer during a decode step: the
+    step's sums (or gathered logits) are wrong and must not be used.  The reference hangs in this
+    situation (core/inference_context.py:54); here the step finishes and the host raises this."""
+
+    def __init__(self, what: str, status: int, rank: int):
+        super().__init__(f"{what}: rank {rank} gave up waiting for rank {status - 1} "
+                         f"(status word {status}); this step's results are invalid")
+        self.status, self.rank = status, rank
+
+
 class IpcAllReduce:
     """Communicator of the one-shot all-reduce.  `exchange(handle: bytes) -> List[bytes]` must
     return every rank's handle in rank order (a host-side all-gather)."""
@@ -71,23 +82,37 @@ class IpcAllReduce:
     def set_timeout_ms(self, ms: float):
         nv.check("mv_allreduce_set_timeout_ms", nv.lib().mv_allreduce_set_timeout_ms(self._comm, float(ms)))
 
+    SELF_TEST_ROUNDS = 6
+
+    @staticmethod
+    def _self_test_rows(rank: int, rnd: int, n: int) -> torch.Tensor:
+        """What `rank` contributes in round `rnd` (CPU, fp32): small integers that differ per rank,
+        per round and per column, all exactly representable in bf16, and so is every sum of up to 8
+        of them - a stale slot of an earlier round or another rank's slot read twice gives a wrong sum."""
+        col = torch.arange(n, dtype=torch.float32) % 7
+        return (col + float(3 * rank + 1) + float(5 * (rnd % 3)))[None]
+
     def self_test(self, timeout_ms: float = 3000.0) -> bool:
-        """One known sum through the mapped buffers, every rank at once: rank r contributes r + 1 in
-        every element, so each rank must read world * (world + 1) / 2 everywhere, twice in a row (both
-        data slots), with no wait timing out.  Run by all ranks right after `connect`, before the
-        communicator is trusted with a decode step: a link that maps but does not deliver ends
-        here, in seconds, instead of in a step that waits out the full timeout 64 times."""
+        """Known sums through the mapped buffers, every rank at once, SELF_TEST_ROUNDS times in a row
+        with no host synchronisation in between (so each of the two data slots is reused while peers
+        may still be a round behind) and with data that differs per rank, round and column; every
+        rank must read the exact rank-ordered sum every time, with no wait timing out.  Run by all
+        ranks right after `connect`, before the communicator is trusted with a decode step: a link
+        that maps but does not deliver, or delivers a flag before its data, ends here, in seconds,
+        instead of in a step that waits out the full timeout 64 times or returns wrong sums."""
         import os
         n = min(self.max_n, 1024)
-        want = float(self.world * (self.world + 1) // 2)
         self.set_timeout_ms(timeout_ms)
         ok = True
         try:
-            for _ in range(2):
-                x = torch.full((1, n), float(self.rank + 1), dtype=torch.bfloat16, device="cuda")
+            xs = [self._self_test_rows(self.rank, r, n).to(torch.bfloat16).to("cuda")
+                  for r in range(self.SELF_TEST_ROUNDS)]
+            for x in xs:
                 self.all_reduce(x)
-                torch.cuda.synchronize()
-                ok = ok and bool((x.float() == want).all())
+            torch.cuda.synchronize()
+            for r, x in enumerate(xs):
+                want = sum(self._self_test_rows(q, r, n) for q in range(self.world))
+                ok = ok and bool((x.float().cpu() == want).all())
             ok = ok and self.status() == 0
         except Exception:
             ok = False
@@ -96,10 +121,17 @@ class IpcAllReduce:
         return ok
 
     def status(self) -> int:
-        """0 unless a wait for a peer timed out since the communicator was made (synchronises)."""
+        """0 unless a wait for a peer timed out since the communicator was made.  A plain read of a
+        host word the kernels write: it does not wait, so it speaks for the steps the caller has
+        already waited for (e.g. through the read-back of their tokens)."""
         st = ctypes.c_int(0)
         nv.check("mv_allreduce_status", nv.lib().mv_allreduce_status(self._comm, ctypes.byref(st)))
         return st.value
+
+    def raise_if_timed_out(self, what: str = "tensor-parallel exchange"):
+        st = self.status()
+        if st:
+            raise ExchangeTimeout(what, st, self.rank)
 
     def close(self):
         if self._comm:
@@ -174,20 +206,23 @@ class IpcAllGather(IpcAllReduce):
         return out
 
     def self_test(self, timeout_ms: float = 3000.0) -> bool:
-        """Rank r sends r + 1 in every element of its slice; every rank must read q + 1 in slice q,
-        twice in a row (both data slots), with no wait timing out."""
+        """Rank r sends rows that differ per rank, round and column (`_self_test_rows`); every rank
+        must read rank q's row in slice q, SELF_TEST_ROUNDS times in a row without host
+        synchronisation in between (both data slots reused), with no wait timing out."""
         import os
         n = min(self.max_n, 1024)
         self.set_timeout_ms(timeout_ms)
         ok = True
         try:
-            want = torch.arange(1, self.world + 1, dtype=torch.float32, device="cuda").repeat_interleave(n)[None]
-            for _ in range(2):
-                x = torch.full((1, n), float(self.rank + 1), dtype=torch.bfloat16, device="cuda")
-                out = torch.zeros(1, self.world * n, dtype=torch.bfloat16, device="cuda")
+            xs = [self._self_test_rows(self.rank, r, n).to(torch.bfloat16).to("cuda")
+                  for r in range(self.SELF_TEST_ROUNDS)]
+            outs = [torch.zeros(1, self.world * n, dtype=torch.bfloat16, device="cuda") for _ in xs]
+            for x, out in zip(xs, outs):
                 self.gather(x, out)
-                torch.cuda.synchronize()
-                ok = ok and bool((out.float() == want).all())
+            torch.cuda.synchronize()
+            for r, out in enumerate(outs):
+                want = torch.cat([self._self_test_rows(q, r, n) for q in range(self.world)], dim=1)
+                ok = ok and bool((out.float().cpu() == want).all())
             ok = ok and self.status() == 0
         except Exception:
             ok = False
@@ -215,6 +250,9 @@ class DistAllReduce:
 
     def status(self) -> int:
         return 0
+
+    def raise_if_timed_out(self, what: str = ""):
+        pass    # torch.distributed raises (or aborts the process) by itself
 
     def close(self):
         pass

@@ -8,7 +8,8 @@ executes from the reference:
   * core/paged_attention.py PrecomputedRotaryEmbedding, core/layer/rope.py RoPE.forward;
   * core/cache_manager.py KVCacheManager (device="cpu");
   * core/layer/model_graph.py ModelGraphRunner._mlp (static, eager);
-  * core/scheduler.py Scheduler + core/sequence.py Sequence with a stub tokenizer.
+  * core/scheduler.py Scheduler + core/sequence.py Sequence with a stub tokenizer;
+  * core/layer/sampler.py Sampler._sample_impl (static, eager) under torch.manual_seed.
 Only inputs and outputs (data) are stored; no reference source text.
 
 Usage:  cd /tmp && python /root/repo/tests/golden/generate_golden.py
@@ -282,8 +283,40 @@ def gen_scheduler():
         json.dump({"lens": lens, "max_batch_size": 4, "max_prefill_tokens": 200, "log": log}, f)
 
 
+def gen_sampler():
+    """core/layer/sampler.py:21-43 run as it stands (the static method, eagerly): 40 000 draws per
+    row of logits.  Individual draws depend on torch's generator, so what is stored is the count
+    per vocabulary index - the empirical distribution - for rows that exercise each stage: an
+    ordinary row, a row with equal logits inside the kept set and across the top-k boundary, and
+    a top_p so small that only the first candidate survives."""
+    from core.layer.sampler import Sampler
+
+    n = 40000
+    g = torch.Generator().manual_seed(400)
+    rows = [
+        ((torch.randn(64, generator=g) * 2).to(torch.bfloat16), 0.8, 0.9, 20),
+        (torch.tensor([0.5, 3.0, 3.0, -1.0, 2.0, 2.0, 2.0, 0.25, 1.0, 1.0, 1.0, 1.0, -4.0, 0.0, 2.5, -2.0] * 2)
+         .to(torch.bfloat16), 1.0, 0.97, 12),
+        ((torch.randn(48, generator=g) * 1.5).to(torch.bfloat16), 0.7, 1e-6, 10),
+    ]
+    out = {"n_cases": np.int64(len(rows)), "draws": np.int64(n)}
+    for ci, (logits, temp, top_p, top_k) in enumerate(rows):
+        torch.manual_seed(500 + ci)
+        ids = Sampler._sample_impl(logits.float()[None].expand(n, -1).contiguous(), torch.full((n,), temp),
+                                   torch.full((n,), top_p), top_k)
+        counts = torch.bincount(ids, minlength=logits.numel())
+        out.update({f"c{ci}_logits": u16(logits), f"c{ci}_temperature": np.float64(temp),
+                    f"c{ci}_top_p": np.float64(top_p), f"c{ci}_top_k": np.int64(top_k),
+                    f"c{ci}_counts": counts.numpy().astype(np.int64),
+                    f"c{ci}_support": torch.nonzero(counts).flatten().numpy().astype(np.int64)})
+    np.savez_compressed(os.path.join(OUT, "sampler.npz"), **out)
+
+
 if __name__ == "__main__":
-    for fn in (gen_norms, gen_swiglu, gen_rotary, gen_cache_traces, gen_mlp, gen_scheduler):
+    only = set(sys.argv[1:])
+    for fn in (gen_norms, gen_swiglu, gen_rotary, gen_cache_traces, gen_mlp, gen_scheduler, gen_sampler):
+        if only and fn.__name__ not in only:
+            continue
         print("generating", fn.__name__, flush=True)
         fn()
     print("done ->", OUT)

@@ -97,3 +97,24 @@ def test_unappend_restores_the_state_before_the_append(mv):
         assert (mgr.append(1), mgr.append(2)) == (s1, s2)
     else:
         raise AssertionError("the pool never ran out")
+
+
+def test_unappend_after_a_whole_page_prompt_under_strict_reference_keeps_the_prompt_page(mv):
+    """strict_reference records the last page of a prompt of exactly k pages as empty (the reference's
+    alloc), so the first append returns offset 0 of that EXISTING page.  Taking that append back must
+    only lower the fill count: the page holds prompt rows and stays with the sequence."""
+    import copy
+
+    from micro_vllm_amd.core.cache_manager import KVCacheManager
+
+    mgr = KVCacheManager(6, 16, 1, 1, 8, dtype=torch.float32, device="cpu", max_tokens=64, max_batch_size=2,
+                         strict_reference=True)
+    assert mgr.alloc(1, 32)[0]              # two whole pages
+    pages = list(mgr._blocks[1])
+    before = (copy.deepcopy(mgr._blocks), dict(mgr._pos), list(mgr._free))
+    slot = mgr.append(1)
+    assert slot == pages[-1] * 16           # offset 0 of the prompt's last page, no page opened
+    mgr.unappend(1, slot)
+    assert (mgr._blocks, dict(mgr._pos), list(mgr._free)) == before
+    assert mgr._blocks[1] == pages and pages[-1] not in mgr._free
+    assert mgr.append(1) == slot
