@@ -195,6 +195,32 @@ int mv_decode_chain(const mv_chain_phase* phases, int nphase, int m, void* works
                     size_t workspace_bytes, mv_stream_t stream);
 int mv_decode_chain_status(const void* workspace, int* status_out);
 
+/* The QKV projection (with its RMSNorm prologue) and the paged attention of a decode step of 1, 2 or
+ * 4 rows in ONE launch: what mv_wgemm_norm (x, ln_w, eps, w_tiles, bias -> qkv [m, n], n = (hq + 2 hkv) d)
+ * followed by mv_paged_attn_decode (q | k | v = the columns of qkv) computes, bit for bit - the same
+ * strips in the same wave shape, the same row assignment, softmax arithmetic and split merge - with
+ * the attention's page ids and key/value rows requested at the very start of the launch, before q
+ * exists.  core/layer/model_graph.py:143-147 and :161-168 of one block.  No counterpart in the
+ * reference (which cannot start flash-attn's loads before cuBLAS has finished).
+ * One 512-thread workgroup per (row, kv head, split), all resident at once: MV_ERR_UNSUPPORTED (issue
+ * the two launches instead) unless CUs / 2 < m * hkv * num_splits <= CUs, num_splits >= 2, the head
+ * shape is one the dot-product attention form serves with (d, hq / hkv) in {128} x {1, 2, 4} or
+ * {64} x {1, 4}, and the stand-alone projection would run this shape as whole strips on 8 waves.
+ * qkv is written (write-through) and may be read by later launches.  attn_workspace: as for
+ * mv_paged_attn_decode.  sync_workspace: mv_qkv_attn_workspace_bytes() bytes, 16-byte aligned,
+ * zero-filled once by the caller, for launches that are stream-ordered with each other; the launch
+ * needs the whole GPU to itself (a workgroup waits for the others of its kv head).  A wait of more
+ * than 2 s gives up, the results are then wrong, and *status_word - any int the device can write,
+ * e.g. pinned host memory, zero before the first launch - is set to 1 + the workgroup that gave up. */
+size_t mv_qkv_attn_workspace_bytes(void);
+int mv_qkv_attn_decode(const void* x, int64_t ldx, const void* ln_w, float eps, const void* w_tiles,
+                       const void* bias, void* qkv, int64_t ld_qkv, int m, int n, int k, void* k_cache,
+                       void* v_cache, const void* rot_cos, const void* rot_sin, int rot_max_pos,
+                       const int32_t* cache_seqlens, const int32_t* block_table, int bt_stride, void* out,
+                       void* attn_workspace, size_t attn_workspace_bytes, void* sync_workspace,
+                       size_t sync_workspace_bytes, int* status_word, int hq, int hkv, int d, int page,
+                       int num_pages, float scale, int num_splits, mv_stream_t stream);
+
 /* Launch-shape knobs for experiments (no counterpart in the reference; process-wide, read once
  * per call, safe to set from another thread):
  * key 0 = workgroups per CU the grid is sized for (1..8; 0 = planner, the default);

@@ -71,6 +71,9 @@ PROTOTYPES = {
                                   _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mv_paged_attn_decode_slabs": (_I, [_P, _I, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _Z,
                                         _I, _I, _I, _I, _I, _I, _F, _I, _P]),
+    "mv_qkv_attn_workspace_bytes": (_Z, []),
+    "mv_qkv_attn_decode": (_I, [_P, _L, _P, _F, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _I, _P,
+                                _P, _Z, _P, _Z, _P, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mv_paged_attn_decode_noalloc": (_I, [_P, _L, _P, _P, _L, _P, _P, _P, _P, _I, _P, _P, _I, _P,
                                           _I, _I, _I, _I, _I, _I, _F, _I, _P]),
     "mv_gemm_prefill": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),

@@ -26,6 +26,7 @@ SOURCES = [
     "sampler.hip",
     "allreduce.hip",
     "decode_chain.hip",
+    "qkv_attn.hip",
 ]
 
 # -ffp-contract=off: rounding is part of the parity contract; FMAs are written explicitly

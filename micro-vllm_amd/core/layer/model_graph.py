@@ -21,7 +21,7 @@ from typing import Dict, List
 import torch
 
 from .. import parallel_config as pc
-from ..paged_attention import PagedAttention, paged_attn_decode, paged_attn_decode_slabs
+from ..paged_attention import PagedAttention, paged_attn_decode, paged_attn_decode_slabs, qkv_attn_decode
 from ... import _native as nv
 from ...kernel.linear import (StreamedWeight, add_, chain_phase, decode_chain, embedding, gemm_workspace,
                               wgemm, wgemm_norm, wgemm_postnorm, wgemm_slabs)
@@ -110,6 +110,11 @@ class ModelGraphRunner:
         # batches of more than four rows: attention adds up the QKV projection's k-slabs itself
         # (MVLLM_QKV_SLABS=0: the projection reduces them in a launch of its own, as before)
         self.qkv_slabs = os.environ.get("MVLLM_QKV_SLABS", "1") != "0"
+        # batches of up to four rows on one GPU: QKV projection and attention as one launch whose
+        # key/value rows are requested before q exists (MVLLM_QKV_ATTN=0: two launches, as before;
+        # the same bits either way)
+        self.qkv_attn = os.environ.get("MVLLM_QKV_ATTN", "1") != "0"
+        self._qkv_attn_ok: Dict[tuple, bool] = {}
         self.num_heads = num_heads
         self.kv_num_heads = kv_num_heads
         self.intermediate_size = intermediate_size
@@ -251,6 +256,10 @@ class ModelGraphRunner:
         self._attn_ws = None
         # arrival counter of the chained projections' grid barrier (zero-initialised, never reset)
         self._chain_ws = torch.zeros((L.mv_decode_chain_workspace_bytes() + 3) // 4, dtype=torch.float32, device=dev)
+        # flags of the fused QKV + attention launch (zero-initialised, never reset) and the word it
+        # raises if a wait inside it gives up: pinned host memory, read behind the token read-back
+        self._qa_ws = torch.zeros((L.mv_qkv_attn_workspace_bytes() + 3) // 4, dtype=torch.int32, device=dev)
+        self._qa_status = torch.zeros(1, dtype=torch.int32).pin_memory()
         # this runner's own meeting place for the parts of the greedy pick (zero-initialised tickets)
         self._argmax_ws = torch.zeros((L.mv_argmax_workspace_bytes() + 3) // 4, dtype=torch.float32, device=dev)
 
@@ -356,6 +365,25 @@ class ModelGraphRunner:
         prologue).  Returns (out, pend_out) with the same meaning for the next block."""
         block = self.model.transformer.h[layer_idx]
         ws = self._gemm_ws
+        if pend is None and self.world_size == 1 and self.qkv_attn:
+            splits = self._splits_for(bs, cache_manager)
+            if self._qkv_attn_ok.get((bs, splits)) is not False:
+                k_cache, v_cache = cache_manager.get(layer_idx)
+                ok = qkv_attn_decode(
+                    h, block.ln_1.weight, block.ln_1.eps, block.attn._qkv_w, block.attn._qkv_b, self._qkv[:bs],
+                    self.num_heads, k_cache, v_cache, cache_manager._cache_seqlens_buffer[:bs],
+                    cache_manager._block_table_buffer[:bs], self.attention._cos_pool, self.attention._sin_pool,
+                    num_splits=splits, out=self._attn[:bs], workspace=self._attn_ws,
+                    sync_workspace=self._qa_ws, status_word=self._qa_status)
+                self._qkv_attn_ok[(bs, splits)] = ok
+                if ok:
+                    attn_out = wgemm(self._attn[:bs].reshape(bs, -1), block.attn._o, self._attn_out[:bs],
+                                     workspace=ws)
+                    wgemm_norm(attn_out, block.ln_2.weight, block.ln_2.eps, block.mlp._gu, self._swiglu_out[:bs],
+                               add_r=h, sum_out=self._residual[:bs], swiglu=True, workspace=ws)
+                    wgemm(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs],
+                          residual=self._residual[:bs], workspace=ws)
+                    return self._mlp_out[:bs], None
         if pend is None:
             wgemm_norm(h, block.ln_1.weight, block.ln_1.eps, block.attn._qkv_w, self._qkv[:bs],
                        bias=block.attn._qkv_b, workspace=ws)
@@ -586,6 +614,10 @@ class ModelGraphRunner:
         """Raises kernel.allreduce.ExchangeTimeout if a reduction or logits gather of a finished
         step gave up waiting for a peer (its results are wrong).  A read of two host words: call it
         after waiting for the step, e.g. behind the read-back of its tokens."""
+        st = int(self._qa_status[0])
+        if st:
+            raise RuntimeError(f"a wait inside the fused QKV + attention launch gave up (workgroup {st - 1}): "
+                               "the launch needs the whole GPU; this step's results are invalid")
         if self.world_size > 1:
             for comm, what in ((self._reducer, "all-reduce of a decode step"),
                                (self._gatherer, "logits all-gather of a decode step")):

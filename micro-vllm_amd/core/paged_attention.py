@@ -133,6 +133,51 @@ def paged_attn_decode(q, k_new, v_new, k_cache, v_cache, cache_seqlens, block_ta
     return out
 
 
+def qkv_attn_decode(x, ln_weight, eps, weight, bias, qkv, num_heads, k_cache, v_cache, cache_seqlens,
+                    block_table, rotary_cos, rotary_sin, num_splits, out, workspace, sync_workspace,
+                    status_word, softmax_scale=None):
+    """RMSNorm + QKV projection + paged attention of a decode step in one launch
+    (mv_qkv_attn_decode): `qkv` [B, (Hq + 2 Hkv) D] and `out` [B, Hq, D] end up holding what
+    `wgemm_norm(x, ln_weight, eps, weight, qkv, bias=bias)` followed by `paged_attn_decode` on the
+    columns of `qkv` would have written, bit for bit.  Returns False, having launched nothing, when
+    the library does not fuse this shape (the caller then issues the two launches).
+    `sync_workspace`: int32 tensor of mv_qkv_attn_workspace_bytes() bytes, zeroed once;
+    `status_word`: pinned int32 host tensor the kernel writes if a wait inside it times out."""
+    assert x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 2 and x.stride(1) == 1
+    B, K = x.shape
+    NB, page, Hkv, D = k_cache.shape
+    Hq = num_heads
+    n = (Hq + 2 * Hkv) * D
+    assert weight.n == n and weight.k == K and not weight.swiglu
+    assert qkv.dtype == torch.bfloat16 and qkv.shape == (B, n) and qkv.stride(1) == 1
+    assert out.is_contiguous() and out.shape == (B, Hq, D) and out.dtype == torch.bfloat16
+    assert ln_weight.dtype == torch.bfloat16 and ln_weight.numel() == K and ln_weight.is_contiguous()
+    assert bias is None or (bias.dtype == torch.bfloat16 and bias.numel() == n and bias.is_contiguous())
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == v_cache.shape
+    assert cache_seqlens.dtype == torch.int32 and block_table.dtype == torch.int32
+    assert block_table.stride(1) == 1 and cache_seqlens.is_contiguous() and block_table.shape[0] == B
+    assert rotary_cos is None or (rotary_cos.dtype == torch.bfloat16 and rotary_cos.shape[1] == D // 2
+                                  and rotary_cos.is_contiguous() and rotary_sin.is_contiguous())
+    assert status_word.dtype == torch.int32 and (status_word.is_pinned() or status_word.is_cuda)
+    L = nv.lib()
+    ldx = x.stride(0) if B > 1 else max(K, x.stride(0))
+    ldq = qkv.stride(0) if B > 1 else max(n, qkv.stride(0))
+    scale = float(softmax_scale) if softmax_scale is not None else float(D) ** -0.5
+    rc = L.mv_qkv_attn_decode(
+        x.data_ptr(), ldx, ln_weight.data_ptr(), float(eps), weight.tiles.data_ptr(), nv.ptr(bias),
+        qkv.data_ptr(), ldq, B, n, K, k_cache.data_ptr(), v_cache.data_ptr(), nv.ptr(rotary_cos),
+        nv.ptr(rotary_sin), rotary_cos.shape[0] if rotary_cos is not None else 0, cache_seqlens.data_ptr(),
+        block_table.data_ptr(), block_table.stride(0), out.data_ptr(),
+        workspace.data_ptr() if workspace is not None else None,
+        workspace.numel() * workspace.element_size() if workspace is not None else 0,
+        sync_workspace.data_ptr(), sync_workspace.numel() * sync_workspace.element_size(),
+        status_word.data_ptr(), Hq, Hkv, D, page, NB, scale, int(num_splits), nv.stream_ptr())
+    if rc == nv.MV_ERR_UNSUPPORTED:
+        return False
+    nv.check("mv_qkv_attn_decode", rc)
+    return True
+
+
 def paged_attn_decode_slabs(qkv_slabs, ksplit, qkv_bias, num_heads, k_cache, v_cache, cache_seqlens,
                             block_table, rotary_cos=None, rotary_sin=None, softmax_scale=None,
                             num_splits=0, out=None, workspace=None):
