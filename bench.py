@@ -54,8 +54,6 @@ def parse():
     ap.add_argument("--no-bs32", action="store_true", help="skip the batch-32 legs of the report")
     ap.add_argument("--no-engine", action="store_true",
                     help="skip the InferenceEngine leg of the report (32 requests, prefill and decode mixed)")
-    ap.add_argument("--chain", action="store_true",
-                    help="A/B switch: one launch per block for the projections of a small batch (grid barriers)")
     ap.add_argument("--as-rank-of", type=int, default=0, metavar="N",
                     help="one process, no peers: build and run rank 0 of a tensor-parallel group of N "
                          "(the several-ranks launch sequence; its reductions sum one partial)")
@@ -90,7 +88,7 @@ def build(args, dev, world):
         model, layers, cfg.num_attention_heads // world, cfg.head_dim,
         cfg.num_key_value_heads // world, cfg.hidden_size, cfg.intermediate_size // world, dev,
         max_batch_size=args.bs, max_blocks=max(32, blocks_per_seq), release_source_weights=True,
-        chain=args.chain, **alone)
+        **alone)
     mgr = KVCacheManager(args.bs * blocks_per_seq + 2, 256, layers, cfg.num_key_value_heads // world,
                          cfg.head_dim, dtype=torch.bfloat16, device=dev,
                          max_tokens=blocks_per_seq * 256, max_batch_size=args.bs)
@@ -160,42 +158,19 @@ def prefill_leg(args, cfg, layers, runner, dev, reps=3):
 
 def projection_timing(runner, bs, layers, reps=20):
     """Average duration of the projection launches of one decode step, issued exactly as the step
-    issues them - chained four to a launch with the norm prologues (bs <= 4), or with the slab
-    reduction + norm launches (bs > 4), bias / SwiGLU / residual epilogues - back to back as one
-    hipGraph, bracketed by HIP events on
+    issues them - with the norm prologues (bs <= 4), or with the slab reduction + norm launches
+    (bs > 4), bias / SwiGLU / residual epilogues - back to back as one hipGraph, bracketed by HIP
+    events on
     the stream the graph is launched on.  Attention, embedding and the token pick are left out, so the
     figure is the dominant kernel's own; the ~0.2 us between graph nodes is inside it."""
     import ctypes
     from micro_vllm_amd import _native as nv
-    from micro_vllm_amd.kernel.linear import chain_phase, decode_chain, wgemm, wgemm_norm, wgemm_postnorm, wgemm_slabs
+    from micro_vllm_amd.kernel.linear import wgemm, wgemm_norm, wgemm_postnorm, wgemm_slabs
 
     tr = runner.model.transformer
-    chained = bs <= 4 and bool(runner._chain_ok.get(bs))
     ws = runner._gemm_ws
     h, normed, resid = runner._hidden0[:bs], runner._normed[:bs], runner._residual[:bs]
     attn = runner._attn[:bs].reshape(bs, -1)
-
-    def chained_pass():     # ModelGraphRunner._decode_chained without its attention launches
-        b0 = tr.h[0]
-        wgemm_norm(h, b0.ln_1.weight, b0.ln_1.eps, b0.attn._qkv_w, runner._qkv[:bs], bias=b0.attn._qkv_b,
-                   workspace=ws)
-        h_in = h
-        for li in range(layers):
-            b = tr.h[li]
-            ph = [chain_phase(attn, b.attn._o, runner._attn_out[:bs]),
-                  chain_phase(runner._attn_out[:bs], b.mlp._gu, runner._swiglu_out[:bs], ln_weight=b.ln_2.weight,
-                              eps=b.ln_2.eps, add_r=h_in, sum_out=resid, swiglu=True),
-                  chain_phase(runner._swiglu_out[:bs], b.mlp._d, runner._mlp_out[:bs], residual=resid)]
-            if li + 1 < layers:
-                nb = tr.h[li + 1]
-                ph.append(chain_phase(runner._mlp_out[:bs], nb.attn._qkv_w, runner._qkv[:bs],
-                                      ln_weight=nb.ln_1.weight, eps=nb.ln_1.eps, bias=nb.attn._qkv_b))
-            else:
-                ph.append(chain_phase(runner._mlp_out[:bs], runner._lm_head, runner._logits[:bs],
-                                      ln_weight=tr.ln_f.weight, eps=tr.ln_f.eps))
-            assert decode_chain(ph, bs, runner._chain_ws)
-            h_in = runner._mlp_out[:bs]
-        return layers + 1
 
     def tp_pass():          # ModelGraphRunner._decode_tp without its attention and reduction launches
         slabs = getattr(runner._reducer, "takes_slabs", False)
@@ -221,8 +196,6 @@ def projection_timing(runner, bs, layers, reps=20):
         return 4 * layers + 1
 
     def one_pass():
-        if chained:
-            return chained_pass()
         if runner.world_size > 1:
             return tp_pass()
         n = 0
@@ -284,8 +257,6 @@ def roofline_block(runner, cfg, bs, layers, world, weight_bytes, step_bytes, ste
     per_launch = weight_bytes / n_launch
     ach = per_launch / t_k / 1e9
     kname = "wgemm_dot_kernel" if bs <= 4 else "wgemm_mfma_kernel"
-    if bs <= 4 and runner._chain_ok.get(bs):
-        kname = "decode_chain_kernel"    # one launch = O, gate/up, down and the next QKV (or the LM head)
     traffic, source = None, None
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tf):

@@ -8,8 +8,7 @@
  * and all launches are legal under HIP stream capture.  The set-up and tear-down
  * calls of the communicators (mv_allreduce_init / _connect / _destroy,
  * mv_allgather_init) do allocate, map and free device memory and wait for the
- * device; mv_decode_chain_status copies a word back and waits for it.  They say
- * so where they are declared.  The entry points keep no state on the device
+ * device.  They say so where they are declared.  The entry points keep no state on the device
  * between calls except in the buffers the caller passes, so calls on different
  * streams (or threads) are independent as long as they are given different
  * workspaces; the one exception is mv_paged_attn_decode_noalloc, which says so.  All tensors are bf16 unless a parameter
@@ -153,47 +152,6 @@ int mv_wgemm_postnorm(const void* x, int64_t ldx, const void* w_tiles, const voi
                       const void* residual, int64_t ld_res, void* y, int64_t ldy, const void* ln_w,
                       float eps, void* normed, int64_t ld_normed, int norm_flags, int m, int n, int k,
                       void* workspace, size_t workspace_bytes, mv_stream_t stream);
-
-/* Up to four dependent projections of a decode step (1 <= M <= 4 rows) in ONE launch, separated
- * by grid barriers instead of launch boundaries; every wave requests the next projection's first
- * weight tiles before it waits, so HBM keeps streaming across the hand-over.  Each phase is what
- * mv_wgemm / mv_wgemm_norm compute (same field meanings; results bit-identical to those launches):
- *   x' = x                                 (ln_w == NULL)
- *   x' = rmsnorm(x) * ln_w                 (ln_w, add_r == NULL)
- *   s = x + add_r; sum_out = bf16(s); x' = rmsnorm(s) * ln_w     (add_r, sum_out, ln_w)
- *   y = epilogue(x' @ W^T): + bias, + residual, or SwiGLU (flags = MV_GEMM_SWIGLU)
- * Phase p + 1 may read anything phase p wrote (y, sum_out).  The decode step uses it for
- * O -> gate/up (+add+norm, SwiGLU) -> down (+residual) -> next block's QKV (+norm) | LM head:
- * core/layer/model_graph.py:171, :213 + :183-184, :185 + :219, :143-147 of the next block | :222-223.
- * workspace: mv_decode_chain_workspace_bytes() bytes, 16-byte aligned, zero-filled once by the
- * caller; launches that share a workspace must be stream-ordered.  The launch needs the whole GPU
- * (one workgroup per CU, all resident): a wait of more than 2 s for the other workgroups gives up and
- * sets the status word mv_decode_chain_status reads (0 = never; a synchronising call).
- * MV_ERR_UNSUPPORTED: a projection the stand-alone kernel would split along k, or rows that do not
- * fit LDS - issue the phases as separate launches then. */
-typedef struct mv_chain_phase {
-    const void* x;
-    int64_t ldx;
-    const void* add_r;
-    int64_t ld_add_r;
-    const void* ln_w;
-    float eps;
-    int norm_flags;
-    void* sum_out;
-    int64_t ld_sum_out;
-    const void* w_tiles;
-    const void* bias;
-    const void* residual;
-    int64_t ld_res;
-    void* y;
-    int64_t ldy;
-    int n, k;
-    int flags;
-} mv_chain_phase;
-size_t mv_decode_chain_workspace_bytes(void);
-int mv_decode_chain(const mv_chain_phase* phases, int nphase, int m, void* workspace,
-                    size_t workspace_bytes, mv_stream_t stream);
-int mv_decode_chain_status(const void* workspace, int* status_out);
 
 /* The QKV projection (with its RMSNorm prologue) and the paged attention of a decode step of 1, 2 or
  * 4 rows in ONE launch: what mv_wgemm_norm (x, ln_w, eps, w_tiles, bias -> qkv [m, n], n = (hq + 2 hkv) d)

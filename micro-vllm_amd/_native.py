@@ -25,13 +25,6 @@ MV_GEMM_SLABS = 4
 MV_GEMM_PLAN_SLABS = 8
 MV_NORM_VAR_FROM_ROUNDED = 1
 
-class ChainPhase(ctypes.Structure):
-    """mv_chain_phase of include/mvllm.h."""
-    _fields_ = [("x", c_void_p), ("ldx", c_int64), ("add_r", c_void_p), ("ld_add_r", c_int64),
-                ("ln_w", c_void_p), ("eps", c_float), ("norm_flags", c_int), ("sum_out", c_void_p),
-                ("ld_sum_out", c_int64), ("w_tiles", c_void_p), ("bias", c_void_p), ("residual", c_void_p),
-                ("ld_res", c_int64), ("y", c_void_p), ("ldy", c_int64), ("n", c_int), ("k", c_int),
-                ("flags", c_int)]
 
 
 _P = c_void_p
@@ -54,9 +47,6 @@ PROTOTYPES = {
     "mv_interleave_rows8": (_I, [_P, _P, _P, _I, _I, _P]),
     "mv_wgemm_workspace_bytes": (_Z, [_I, _I, _I]),
     "mv_wgemm_tune": (_I, [_I, _I]),
-    "mv_decode_chain_workspace_bytes": (_Z, []),
-    "mv_decode_chain": (_I, [ctypes.POINTER(ChainPhase), _I, _I, _P, _Z, _P]),
-    "mv_decode_chain_status": (_I, [_P, ctypes.POINTER(c_int)]),
     "mv_wgemm": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P, _Z, _I, _P]),
     "mv_wgemm_norm": (_I, [_P, _L, _P, _L, _P, _F, _P, _L, _I, _P, _P, _P, _L, _P, _L, _I, _I, _I, _P,
                            _Z, _I, _P]),

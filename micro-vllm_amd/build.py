@@ -25,7 +25,6 @@ SOURCES = [
     "gemm_prefill.hip",
     "sampler.hip",
     "allreduce.hip",
-    "decode_chain.hip",
     "qkv_attn.hip",
 ]
 

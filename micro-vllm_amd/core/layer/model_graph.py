@@ -23,7 +23,7 @@ import torch
 from .. import parallel_config as pc
 from ..paged_attention import PagedAttention, paged_attn_decode, paged_attn_decode_slabs, qkv_attn_decode
 from ... import _native as nv
-from ...kernel.linear import (StreamedWeight, add_, chain_phase, decode_chain, embedding, gemm_workspace,
+from ...kernel.linear import (StreamedWeight, add_, embedding, gemm_workspace,
                               wgemm, wgemm_norm, wgemm_postnorm, wgemm_slabs)
 from ...kernel.rmsnorm_add import rmsnorm_
 from ...kernel.rmsnorm_residual import rmsnorm_residual_gemm
@@ -86,15 +86,11 @@ class ModelGraphRunner:
                  hidden_dim: int, intermediate_size: int, device: str, max_batch_size: int = 32,
                  dtype: torch.dtype = torch.bfloat16, top_k: int = 1000, fused: bool = True,
                  max_blocks: int = 32, exact_rope: bool = False, release_source_weights: bool = False,
-                 reducer=None, tp_rank: int = None, tp_world: int = None, chain: bool = False):
+                 reducer=None, tp_rank: int = None, tp_world: int = None):
         """num_heads / kv_num_heads / intermediate_size are the PER-RANK values (already divided
         by the tensor-parallel world size), intermediate_size counting gate and up together,
         exactly as the reference's engine passes them (core/engine.py:108-114).
 
-        `chain=True` issues the projections of a small batch (bs <= 4, one rank) as one launch per
-        block with grid barriers between them (`_decode_chained`) instead of separate launches;
-        the results are the same bits either way.  Off by default: measured on MI355X the two are
-        equally fast (both stream weights at about 94 % of what a copy kernel reaches).
         `reducer` (kernel/allreduce.py interface) replaces the process group's reduction, and
         `tp_rank` / `tp_world` the process group's rank and size: a single process can then run
         the step of any one rank of a tensor-parallel group (tests, per-rank benchmarks)."""
@@ -106,14 +102,16 @@ class ModelGraphRunner:
             assert reducer is not None and 0 <= tp_rank < tp_world
             self.rank, self.world_size = tp_rank, tp_world
         self._reducer = reducer
-        self.chain = chain
         # batches of more than four rows: attention adds up the QKV projection's k-slabs itself
         # (MVLLM_QKV_SLABS=0: the projection reduces them in a launch of its own, as before)
         self.qkv_slabs = os.environ.get("MVLLM_QKV_SLABS", "1") != "0"
-        # batches of up to four rows on one GPU: QKV projection and attention as one launch whose
-        # key/value rows are requested before q exists (MVLLM_QKV_ATTN=0: two launches, as before;
-        # the same bits either way)
-        self.qkv_attn = os.environ.get("MVLLM_QKV_ATTN", "1") != "0"
+        # batches of 1, 2 or 4 rows on one GPU: QKV projection and attention as one launch whose
+        # key/value rows are requested while the projection streams (MVLLM_QKV_ATTN=1).  The same
+        # bits either way; off by default because it measured slower on MI355X (3.16 against 3.02 ms
+        # per step of the 8B shape): weights and rows share one HBM pipe, so the rows lengthen the
+        # projection phase by what they shorten the attention phase, and the hand-over of q costs
+        # what the launch boundary did.
+        self.qkv_attn = os.environ.get("MVLLM_QKV_ATTN", "0") == "1"
         self._qkv_attn_ok: Dict[tuple, bool] = {}
         self.num_heads = num_heads
         self.kv_num_heads = kv_num_heads
@@ -154,7 +152,6 @@ class ModelGraphRunner:
         self.uneven_ratio = None
         self._is_graph_ready = False
         self._num_splits: Dict[int, int] = {}
-        self._chain_ok: Dict[int, bool] = {}
 
     # ------------------------------------------------------------------ init
     def prepare_weights(self):
@@ -254,8 +251,6 @@ class ModelGraphRunner:
             need = max([need] + [L.mv_wgemm_postnorm_workspace_bytes(m, n, k) for m in range(1, max_b + 1)])
         self._gemm_ws = gemm_workspace(dev, max(need, 16))
         self._attn_ws = None
-        # arrival counter of the chained projections' grid barrier (zero-initialised, never reset)
-        self._chain_ws = torch.zeros((L.mv_decode_chain_workspace_bytes() + 3) // 4, dtype=torch.float32, device=dev)
         # flags of the fused QKV + attention launch (zero-initialised, never reset) and the word it
         # raises if a wait inside it gives up: pinned host memory, read behind the token read-back
         self._qa_ws = torch.zeros((L.mv_qkv_attn_workspace_bytes() + 3) // 4, dtype=torch.int32, device=dev)
@@ -425,9 +420,6 @@ class ModelGraphRunner:
         h = embedding(self.model.transformer.wte.weight, input_ids, self._hidden0[:bs])
         if self.fused and self.world_size > 1 and self._reducer.fits(bs, self.hidden_dim):
             logits = self._decode_tp(h, bs, cache_manager)
-        elif self.fused and bs <= 4 and self.chain and self.world_size == 1 and \
-                (logits := self._decode_chained(h, bs, cache_manager)) is not None:
-            pass
         elif self.fused and bs <= 4:
             pend = None
             for layer_idx in range(self.num_layers):
@@ -518,54 +510,6 @@ class ModelGraphRunner:
                            normed, residual=self._residual[:bs], var_from_rounded=True, workspace=ws)
             h = self._mlp_out[:bs]
         return wgemm(normed, self._lm_head, self._logits[:bs], workspace=ws)
-
-    def _decode_chained(self, h, bs, cache_manager):
-        """bs <= 4 on one GPU: after a block's attention, its O, gate/up and down projections and the
-        NEXT block's QKV projection (the LM head after the last block) run as ONE launch with grid
-        barriers between them (`decode_chain`), so a block is two launches - attention, projections -
-        instead of five.  Same arithmetic, bit for bit, as `_layer_norm_fused`.  Returns None, having
-        launched nothing, when the library does not chain this model's shapes."""
-        tr = self.model.transformer
-        blocks = tr.h
-        hq, hkv, d = self.num_heads, self.kv_num_heads, self.head_size
-        qkv, attn_buf = self._qkv[:bs], self._attn[:bs]
-
-        def phases(li, h_in):
-            block = blocks[li]
-            ph = [chain_phase(attn_buf.reshape(bs, -1), block.attn._o, self._attn_out[:bs]),
-                  chain_phase(self._attn_out[:bs], block.mlp._gu, self._swiglu_out[:bs], ln_weight=block.ln_2.weight,
-                              eps=block.ln_2.eps, add_r=h_in, sum_out=self._residual[:bs], swiglu=True),
-                  chain_phase(self._swiglu_out[:bs], block.mlp._d, self._mlp_out[:bs], residual=self._residual[:bs])]
-            if li + 1 < self.num_layers:
-                nb = blocks[li + 1]
-                ph.append(chain_phase(self._mlp_out[:bs], nb.attn._qkv_w, qkv, ln_weight=nb.ln_1.weight,
-                                      eps=nb.ln_1.eps, bias=nb.attn._qkv_b))
-            else:
-                ph.append(chain_phase(self._mlp_out[:bs], self._lm_head, self._logits[:bs],
-                                      ln_weight=tr.ln_f.weight, eps=tr.ln_f.eps))
-            return ph
-
-        if self._chain_ok.get(bs) is False:
-            return None
-        wgemm_norm(h, blocks[0].ln_1.weight, blocks[0].ln_1.eps, blocks[0].attn._qkv_w, qkv,
-                   bias=blocks[0].attn._qkv_b, workspace=self._gemm_ws)
-        for li in range(self.num_layers):
-            k_cache, v_cache = cache_manager.get(li)
-            paged_attn_decode(
-                qkv[:, :hq * d].unflatten(1, (hq, d)), qkv[:, hq * d:(hq + hkv) * d].unflatten(1, (hkv, d)),
-                qkv[:, (hq + hkv) * d:].unflatten(1, (hkv, d)), k_cache, v_cache,
-                cache_manager._cache_seqlens_buffer[:bs], cache_manager._block_table_buffer[:bs],
-                self.attention._cos_pool, self.attention._sin_pool,
-                num_splits=self._splits_for(bs, cache_manager), out=attn_buf, workspace=self._attn_ws)
-            if not decode_chain(phases(li, h), bs, self._chain_ws):
-                # refused before anything ran (shape rule): nothing but the first QKV projection and
-                # one attention launch happened, and the caller redoes the step from the start
-                assert li == 0
-                self._chain_ok[bs] = False
-                return None
-            h = self._mlp_out[:bs]
-        self._chain_ok[bs] = True
-        return self._logits[:bs]
 
     def _decode_tp(self, h, bs, cache_manager):
         """Several ranks, any batch size: each of the two reductions of a block (after the O and

@@ -28,6 +28,24 @@
 #include "attn_decode_shared.h"
 
 #include <atomic>
+#include <type_traits>
+
+#ifdef MV_QA_STAMP
+namespace mv {
+// Phase stamps (build variant for tools/stamp_qkv_attn.py): the constant 100 MHz counter at up to
+// sixteen points of every workgroup, written by its first thread.
+static __device__ unsigned long long g_qstamp[16 * 1024];
+}  // namespace mv
+#define MV_QSTAMP(slot)                                                                  \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        if (threadIdx.x == 0 && blockIdx.x < 1024)                                       \
+            mv::g_qstamp[16 * blockIdx.x + (slot)] = __builtin_amdgcn_s_memrealtime();   \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define MV_QSTAMP(slot) do {} while (0)
+#endif
 
 namespace mv {
 
@@ -64,18 +82,21 @@ struct QaUnit {
 template <int D, int G, int M>
 __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
     constexpr int GW = 8;                    // waves of the projection (all of the workgroup)
-    constexpr int U = (M <= 2) ? 4 : 2;      // weight tiles per stage and wave
+    // weight tiles per stage and wave: twice the stand-alone kernel's (the registers of the attention
+    // phase are idle meanwhile, and half the workgroups stream two strips one after the other; the
+    // order of a wave's sums does not depend on it)
+    constexpr int U = (M <= 2) ? 8 : 4;
     constexpr int kAW = 4;                   // waves of the attention body
     constexpr int kAC = 4;                   // row loads per wave per stage
     constexpr int LPR = D / 8, RPI = 64 / LPR, NS = kAW * RPI;
     constexpr int CR = NS * kAC;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ unsigned int s_epoch;
     const AttnArgs& a = qa.at;
 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool attn_wave = wid < kAW;
+    MV_QSTAMP(0);
 
     // ---- who this workgroup is -----------------------------------------------------------
     const int kvh = blockIdx.x % a.hkv;
@@ -85,8 +106,9 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
     const int bh = b * a.hkv + kvh;
     const bool last_split = (split == a.nsplit - 1);
 
-    if (threadIdx.x == 0)
-        s_epoch = __hip_atomic_load(qa.sync + kQaEpoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    // the epoch of this launch: one more than the word the last launch left (written through at its
+    // end, so a plain - scalar - load across the kernel boundary sees it); nothing waits for it here
+    const unsigned int e = qa.sync[kQaEpoch] + 1u;
 
     // ---- attention, part one: everything that does not need q, k, v -------------------------
     const int lr = lane % LPR, tg = lane / LPR;
@@ -100,6 +122,11 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
 #pragma unroll
         for (int i = 0; i < kAC; ++i) pg[i] = bt[min(row_of(c, i) >> a.page_shift, a.bt_stride - 1)];
     };
+    // Waves 4-7 run the same instruction stream with every row address replaced by a line that is
+    // always cache-hot (their lanes' 16 bytes of x): a branch around these requests would make the
+    // compiler's wait for x, further down, cover them too (it counts requests per program path),
+    // and the input transform of every workgroup would sit behind 16.8 MB of cold rows.
+    const uint16_t* hot = qa.x + (threadIdx.x & 255) * 8;
     auto load_rows = [&](uint4(&kb)[kAC], uint4(&vb)[kAC], bool(&ok)[kAC], const int (&pg)[kAC], int c) {
 #pragma unroll
         for (int i = 0; i < kAC; ++i) {
@@ -108,15 +135,13 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
             ok[i] = (t < pos) && page_ok;
             const int64_t off =
                 (((int64_t)(page_ok ? pg[i] : 0) << a.page_shift) + (t & (a.page - 1))) * row_stride + head_off;
-            kb[i] = ld16(a.k_cache + off);
-            vb[i] = ld16(a.v_cache + off);
+            kb[i] = ld16(attn_wave ? a.k_cache + off : hot);
+            vb[i] = ld16(attn_wave ? a.v_cache + off : hot);
         }
     };
-    int pgA[kAC] = {}, pgB[kAC] = {};
-    if (attn_wave) {
-        load_pages(pgA, 0);
-        load_pages(pgB, 1);
-    }
+    int pgA[kAC], pgB[kAC];
+    load_pages(pgA, 0);
+    load_pages(pgB, 1);
 
     // ---- projection: x and the norm weight are requested first (memory answers a wave in order) --
     const int r = lane & 15, q = lane >> 4;
@@ -134,28 +159,6 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
 #pragma unroll
             for (int m = 0; m < M; ++m) pxe[m][j] = ld16(qa.x + (int64_t)m * qa.ldx + c * 8);
             pwe[j] = ld16(qa.ln_w + c * 8);
-        }
-    }
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-
-    // the rows themselves: both stages, then the page ids of the stages after them
-    uint4 kA[kAC] = {}, vA[kAC] = {}, kB[kAC] = {}, vB[kAC] = {};
-    bool okA[kAC] = {}, okB[kAC] = {};
-    uint4 cosv = make_uint4(0, 0, 0, 0), sinv = cosv;
-    const bool rotate = (a.rot_cos != nullptr);
-    const bool first_half = d0 < D / 2;
-    const int dpart = first_half ? d0 + D / 2 : d0 - D / 2;
-    if (attn_wave) {
-        load_rows(kA, vA, okA, pgA, 0);
-        load_pages(pgA, 2);
-        load_rows(kB, vB, okB, pgB, 1);
-        load_pages(pgB, 3);
-        if (rotate) {
-            const int rp = min(max(pos, 0), a.rot_max_pos - 1);
-            const int64_t ro = (int64_t)rp * (D / 2) + (first_half ? d0 : d0 - D / 2);
-            cosv = ld16(a.rot_cos + ro);
-            sinv = ld16(a.rot_sin + ro);
         }
     }
     asm volatile("" ::: "memory");
@@ -199,9 +202,9 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
         }
     };
 
-    int s_unit = jm;                      // members with no strip (more members than strips) still run
-    const bool has_unit = s_unit < SH;    // the loop once on strip 0 and store nothing
-    QaUnit cur = setup(has_unit ? s_unit : 0);
+    // member jm of the head takes strip jm and, where there is one, strip jm + J (the launcher
+    // only admits shapes with one or two strips per member)
+    const QaUnit cur = setup(jm);
     uint4 bufA[U], bufB[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
@@ -282,8 +285,7 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
         }
     }
     __syncthreads();
-    const unsigned int e = s_epoch;
-
+    MV_QSTAMP(1);   // x staged
 #pragma unroll
     for (int i = U; i < 2 * U; ++i) {
         const int t = min(i, cur.last);
@@ -292,31 +294,68 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
     }
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
         qa.qkv, 0, (int)(((int64_t)(M - 1) * qa.ld_qkv + (int64_t)(a.hq + 2 * a.hkv) * D) * 2), 0x00020000);
+    // ---- the rows: declared here, requested (issue_rows) once this workgroup's LAST strip is
+    // multiplied.  Weights and rows share HBM; the strips are what the head's other workgroups wait
+    // for, the rows are needed only when q has come back, so the rows queue behind the weights.
+    // Measured on MI355X (tools/stamp_qkv_attn.py, 8B head shape, 4096 rows, cold caches): the
+    // last strip of a workgroup is multiplied 11.6 us after the launch starts when the rows are
+    // requested only after the hand-over (-DMV_QA_ROWS_LATE), 15-17 us with the rows requested here or
+    // anywhere before - they are 16.8 MB in front of or among 50 MB of weights and cost their share
+    // of the pipe whenever they go - and the launch ends at 24 and 26-27 us against 23 us for the
+    // two stand-alone launches.  That is why the runner leaves this launch switched off. ----------
+    uint4 kA[kAC], vA[kAC], kB[kAC], vB[kAC];
+    bool okA[kAC], okB[kAC];
+    uint4 cosv = make_uint4(0, 0, 0, 0), sinv = cosv;
+    const bool rotate = (a.rot_cos != nullptr);
+    const bool first_half = d0 < D / 2;
+    const int dpart = first_half ? d0 + D / 2 : d0 - D / 2;
+    auto issue_rows = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(kA, vA, okA, pgA, 0);
+        load_pages(pgA, 2);
+        load_rows(kB, vB, okB, pgB, 1);
+        load_pages(pgB, 3);
+        // (uniform: one table or none for the whole launch)
+        const int rp = min(max(pos, 0), max(a.rot_max_pos, 1) - 1);
+        const int64_t ro = (int64_t)rp * (D / 2) + (first_half ? d0 : d0 - D / 2);
+        cosv = ld16(rotate ? a.rot_cos + ro : hot);
+        sinv = ld16(rotate ? a.rot_sin + ro : hot);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     constexpr int kPast = 1 << 24;
-    for (;;) {
-        const int sn = s_unit + J;
-        const bool more = sn < SH;
-        QaUnit nxt = cur;
-        if (more) nxt = setup(sn);
+    // One strip: its sums, and - with another strip to follow - that strip's first two stages
+    // requested on the way.  Wave 4 (which has no rows outstanding, so its wait for its own stores
+    // is short) forms the strip's 16 outputs per row and stores them, two to a dword, write-through.
+    auto run_unit = [&](const QaUnit& cu, const QaUnit& nx, auto more_c) {
+        constexpr bool more = decltype(more_c)::value;
         float acc[M];
 #pragma unroll
         for (int m = 0; m < M; ++m) acc[m] = 0.f;
-        const int npair = (cur.nchunk + 1) >> 1;
+        const int npair = (cu.nchunk + 1) >> 1;
         for (int p = 0; p < npair - 1; ++p) {
-            compute(bufA, cur, 2 * p, acc);
-            load(bufA, cur, 2 * p + 2);
-            compute(bufB, cur, 2 * p + 1, acc);
-            load(bufB, cur, 2 * p + 3);
+            compute(bufA, cu, 2 * p, acc);
+            load(bufA, cu, 2 * p + 2);
+            compute(bufB, cu, 2 * p + 1, acc);
+            load(bufB, cu, 2 * p + 3);
         }
         const int cl = npair > 0 ? 2 * (npair - 1) : kPast;
-        if (more) {
-            compute(bufA, cur, cl, acc);
-            load(bufA, nxt, 0);
-            compute(bufB, cur, cl + 1, acc);
-            load(bufB, nxt, 1);
+        if constexpr (more) {
+            compute(bufA, cu, cl, acc);
+            load(bufA, nx, 0);
+            compute(bufB, cu, cl + 1, acc);
+            load(bufB, nx, 1);
         } else {
-            compute(bufA, cur, cl, acc);
-            compute(bufB, cur, cl + 1, acc);
+            // The rows go out here, behind the last tiles of the last strip and behind the loop
+            // above: requested in front of a loop that also requests, they would be "the oldest
+            // requests" on one path into these waits and absent on the other, and the compiler
+            // would then wait for everything - rows included - before the last tile's product.
+            compute(bufA, cu, cl, acc);
+            compute(bufB, cu, cl + 1, acc);
+#ifndef MV_QA_ROWS_LATE
+            issue_rows();
+#endif
         }
 #pragma unroll
         for (int m = 0; m < M; ++m) {
@@ -328,33 +367,39 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
             for (int m = 0; m < M; ++m) red[(wid * M + m) * 16 + r] = acc[m];
         }
         __syncthreads();
-        if (threadIdx.x < 64) {
-            // the strip's 16 outputs per row, two to a dword, as write-through stores
-            const int m = min((int)threadIdx.x >> 4, M - 1), rr = threadIdx.x & 15;
+        if (wid == 4) {
+            const int m = min(lane >> 4, M - 1), rr = lane & 15;
             float s = 0.f;
 #pragma unroll
             for (int w8 = 0; w8 < GW; ++w8) s += red[(w8 * M + m) * 16 + rr];
-            const int n = cur.strip * 16 + rr;
+            const int n = cu.strip * 16 + rr;
             float t = round_bf16(s);
             if (qa.bias) t = round_bf16(t + bf16_bits_to_f32(qa.bias[n]));
             const uint32_t bits = f32_to_bf16_bits(t);
             const uint32_t nb = __shfl_down(bits, 1, 64);
-            if (has_unit && threadIdx.x < 16 * M && !(rr & 1))
+            if (lane < 16 * M && !(rr & 1))
                 __builtin_amdgcn_raw_buffer_store_b32(bits | (nb << 16), yrs,
                                                       (int)(((int64_t)m * qa.ld_qkv + n) * 2), 0, 16 /*sc1*/);
         }
-        if (!more) break;
-        __syncthreads();
-        s_unit = sn;
-        cur = nxt;
+        if constexpr (more) __syncthreads();   // `red` is reused by the next strip
+    };
+    // (two straight-line paths, so that the compiler's request counts stay exact in each)
+    if (jm + J < SH) {
+        const QaUnit nxt = setup(jm + J);
+        run_unit(cur, nxt, std::true_type{});
+        run_unit(nxt, nxt, std::false_type{});
+    } else {
+        run_unit(cur, cur, std::false_type{});
     }
 
-    // ---- hand-over: this workgroup's outputs are in memory, then its flag goes up ----------------
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0)
-        __hip_atomic_store(qa.sync + kQaFlags + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wid == 0) {   // one wave watches the flags of the head's workgroups; the others sleep at the barrier
+    // ---- hand-over: this workgroup's outputs are in memory, then its flag goes up; the storing
+    // wave does both, and then watches the flags of the head's workgroups while the others sleep
+    // at the barrier ---------------------------------------------------------------------------
+    MV_QSTAMP(2);   // strips done
+    if (wid == 4) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0)
+            __hip_atomic_store(qa.sync + kQaFlags + blockIdx.x, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         for (int iter = 1;; ++iter) {
             bool there = true;
@@ -372,6 +417,10 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
         }
     }
     __syncthreads();
+#ifdef MV_QA_ROWS_LATE
+    issue_rows();   // timing experiment: rows requested only once q is ready
+#endif
+    MV_QSTAMP(4);   // head's flags all up
     // the epoch moves on once every workgroup is past its wait (nobody compares against it again)
     unsigned int passed_before = 0;
     if (threadIdx.x == 0)
@@ -400,6 +449,9 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
         if (rotate) ko = ldq((a.hq + kvh) * D + dpart);
         vnew = ldq((a.hq + a.hkv + kvh) * D + d0);
 
+#ifdef MV_QA_STAMP
+        if (vnew.x != 0x7fc07fc1u) MV_QSTAMP(5);   // q, k, v landed
+#endif
         const int seq_chunks = (max(pos, 0) + CR - 1) / CR;
         const int nchunk = seq_chunks > split ? (seq_chunks - split + a.nsplit - 1) / a.nsplit : 0;
 
@@ -544,12 +596,14 @@ __global__ __launch_bounds__(512) void qkv_attn_kernel(QkvAttnArgs qa) {
             *reinterpret_cast<f32x4_t*>(dst + 4) = (f32x4_t){acc[g][4], acc[g][5], acc[g][6], acc[g][7]};
         }
     }
+    MV_QSTAMP(6);   // rows absorbed, states in LDS
     if (threadIdx.x == 0 && passed_before == gridDim.x - 1u) {
         __hip_atomic_store(qa.sync + kQaPassed, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(qa.sync + kQaEpoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // (threads past the attention waves take no part in the per-head work of the merge)
     finish_states<D, G, NS, kAW>(a, lds, b, kvh, bh, split, attn_wave ? wid : 4096, lane);
+    MV_QSTAMP(7);   // end (last arrivers: output written)
 }
 
 template <int D, int G, int M>
@@ -576,6 +630,12 @@ static int launch_qkv_attn_m(const QkvAttnArgs& qa, int grid, hipStream_t s) {
 }
 
 }  // namespace mv
+
+#ifdef MV_QA_STAMP
+extern "C" int mv_debug_read_qa_stamps(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_qstamp), bytes) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" {
 
@@ -612,10 +672,10 @@ int mv_qkv_attn_decode(const void* x, int64_t ldx, const void* ln_w, float eps, 
     if (dot_form_waves(m, nt, kt) != 8 || dot_form_ksplit(m, nt, kt) != 1) return MV_ERR_UNSUPPORTED;
     const int grid = m * hkv * num_splits;
     const int cus = num_cus();
-    // every workgroup resident at once, most CUs busy, and at least one strip of the head for each of
+    // every workgroup resident at once, most CUs busy, and one or two strips of the head for each of
     // the head's workgroups
     if (num_splits < 2 || num_splits > 128 || grid > cus || 2 * grid <= cus || grid > kQaMaxWgs ||
-        m * hkv > kMaxArrive || (g + 2) * d / 16 < m * num_splits)
+        m * hkv > kMaxArrive || (g + 2) * d / 16 < m * num_splits || (g + 2) * d / 16 > 2 * m * num_splits)
         return MV_ERR_UNSUPPORTED;
     const size_t need = mv_paged_attn_decode_workspace_bytes(m, hq, d, num_splits);
     if (!attn_workspace || attn_workspace_bytes < need || !aligned16(attn_workspace)) return MV_ERR_WORKSPACE;

@@ -847,8 +847,8 @@ static int pick_ksplit(int m, int nt, int kt, bool free_reduce = false) {
 }
 
 // Waves per workgroup of the dot form for a projection of `nunits` units of `kt` k-tiles each (the
-// rule above wgemm_impl's launch explains the numbers).  decode_chain.hip runs projections in the
-// same shape, so that its sums are formed in the same order.
+// rule above wgemm_impl's launch explains the numbers).  qkv_attn.hip runs the QKV projection in
+// the same shape, so that its sums are formed in the same order.
 static int dot_form_waves_for_units(int nunits, int kt) {
     const int cus = num_cus();
     const bool one_long_strip_per_cu = nunits <= cus && nunits * 8 >= cus * 7 && kt >= 128;

@@ -247,49 +247,6 @@ def wgemm_norm(x: torch.Tensor, ln_weight: torch.Tensor, eps: float, w: Streamed
     return out
 
 
-def chain_phase(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor, ln_weight=None, eps: float = 0.0,
-                add_r=None, sum_out=None, var_from_rounded: bool = False, bias=None, residual=None,
-                swiglu: bool = False) -> "nv.ChainPhase":
-    """One projection of `decode_chain`: the arguments of `wgemm` / `wgemm_norm`."""
-    m, k = x.shape
-    assert x.dtype == torch.bfloat16 and x.stride(1) == 1 and k == w.k and swiglu == w.swiglu
-    ncols = w.out_features
-    assert out.shape == (m, ncols) and out.dtype == torch.bfloat16 and out.stride(1) == 1
-    assert (add_r is None) == (sum_out is None) and (add_r is None or ln_weight is not None)
-
-    def ld(t, width):
-        return 0 if t is None else (t.stride(0) if m > 1 else max(width, t.stride(0)))
-
-    if ln_weight is not None:
-        assert ln_weight.dtype == torch.bfloat16 and ln_weight.numel() == k and ln_weight.is_contiguous()
-    if bias is not None:
-        assert bias.dtype == torch.bfloat16 and bias.numel() == w.n and bias.is_contiguous()
-    if residual is not None:
-        assert residual.dtype == torch.bfloat16 and residual.shape == (m, w.n) and residual.stride(1) == 1
-    if add_r is not None:
-        assert add_r.shape == x.shape and sum_out.shape == x.shape
-        assert add_r.dtype == torch.bfloat16 and sum_out.dtype == torch.bfloat16
-    return nv.ChainPhase(
-        x=x.data_ptr(), ldx=ld(x, k), add_r=nv.ptr(add_r), ld_add_r=ld(add_r, k), ln_w=nv.ptr(ln_weight),
-        eps=float(eps), norm_flags=nv.MV_NORM_VAR_FROM_ROUNDED if var_from_rounded else 0,
-        sum_out=nv.ptr(sum_out), ld_sum_out=ld(sum_out, k), w_tiles=w.tiles.data_ptr(), bias=nv.ptr(bias),
-        residual=nv.ptr(residual), ld_res=ld(residual, w.n), y=out.data_ptr(), ldy=ld(out, ncols), n=w.n, k=k,
-        flags=nv.MV_GEMM_SWIGLU if swiglu else nv.MV_GEMM_DEFAULT)
-
-
-def decode_chain(phases, m: int, workspace: torch.Tensor) -> bool:
-    """Up to four dependent projections in one launch (mv_decode_chain).  `workspace`: a
-    zero-initialised buffer of mv_decode_chain_workspace_bytes() that stream-ordered launches share.
-    Returns False - nothing launched - when the library does not chain these shapes."""
-    arr = (nv.ChainPhase * len(phases))(*phases)
-    rc = nv.lib().mv_decode_chain(arr, len(phases), m, workspace.data_ptr(),
-                                  workspace.numel() * workspace.element_size(), nv.stream_ptr())
-    if rc == nv.MV_ERR_UNSUPPORTED:
-        return False
-    nv.check("mv_decode_chain", rc)
-    return True
-
-
 def embedding(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """out[r] = table[ids[r]] (model.transformer.wte(input_ids), model_graph.py:196)."""
     assert table.is_cuda and ids.is_cuda and out.is_cuda

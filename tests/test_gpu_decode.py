@@ -290,40 +290,3 @@ def test_pick_inside_the_captured_step(mv):
     runner.set_sampling([], [])
     logits = runner.forward(ids.to(DEV), mgr, bs)
     assert torch.equal(runner.picked_ids(logits), runner.greedy_ids(logits))
-
-
-@pytest.mark.parametrize("shape,bias", [("tiny-gqa", False), ("tiny-mha", True), ("tiny-d128", False)])
-@pytest.mark.parametrize("bs", [1, 2, 3, 4])
-def test_chained_projections_equal_separate_launches(mv, shape, bias, bs):
-    """One launch per block for O, gate/up, down and the next QKV / LM head (grid barriers between
-    them) against the same projections as separate launches: identical logits and identical KV, bit
-    for bit, eager and replayed from a captured graph; the barrier never timed out."""
-    import ctypes
-    from micro_vllm_amd import _native as nv
-
-    outs, caches = [], []
-    for chain in (True, False):
-        cfg, runner, mgr, ref, ref_cache = build(mv, shape, qkv_bias=bias, n_blocks=24)
-        runner.chain = chain        # (off by default: same speed as separate launches, see the runner)
-        seq_lens = [3, 250, 257, 31][:bs]
-        prefill_random_kv(mgr, ref_cache, seq_lens, seed=11)
-        for sid in range(bs):
-            mgr.append(sid)
-        mgr.cache_batch_data(list(range(bs)), [L + 1 for L in seq_lens])
-        ids = torch.randint(0, cfg.vocab_size, (bs,), generator=torch.Generator().manual_seed(bs))
-        runner._input_ids[:bs] = ids.to(DEV)
-        eager = runner.decode(runner._input_ids[:bs], bs, mgr).clone()
-        if chain:
-            assert runner._chain_ok.get(bs) is True, "the library refused to chain this shape"
-            runner.capture(mgr, batch_sizes=[bs])
-            for _ in range(3):      # replays: the barrier's counter keeps growing across launches
-                replay = runner.forward(ids.to(DEV), mgr, bs).clone()
-            assert torch.equal(replay, eager)
-            st = ctypes.c_int(-1)
-            nv.check("status", nv.lib().mv_decode_chain_status(runner._chain_ws.data_ptr(), ctypes.byref(st)))
-            assert st.value == 0
-        outs.append(eager)
-        caches.append([c.clone() for c in mgr.k_caches] + [c.clone() for c in mgr.v_caches])
-    assert torch.equal(outs[0], outs[1])
-    for a, b in zip(*caches):
-        assert torch.equal(a, b)

@@ -201,21 +201,23 @@ def test_llama3_8b_dimensions_every_stage_on_identical_inputs(mv, bs):
 
 
 def test_llama3_8b_dimensions_fused_equals_separate_kernels(mv):
-    """Norm-in-prologue / epilogue-fused step, the same with the projections of a block chained into
-    one launch (grid barriers between them), and the step made of the reference's separate ops: one
-    set of bits."""
+    """Norm-in-prologue / epilogue-fused step, the same with the QKV projection and the attention of
+    a block issued as one launch (key/value rows requested before q exists), and the step made of the
+    reference's separate ops: one set of bits."""
     outs = []
-    for fused, chain in ((True, False), (True, True), (False, False)):
+    for fused, one_launch in ((True, False), (True, True), (False, False)):
         cfg, runner, mgr, _, _, lens = _build(2, fused=fused)
-        runner.chain = chain
+        runner.qkv_attn = one_launch
         ids = torch.tensor([17, cfg.vocab_size - 2])
         for sid in range(2):
             mgr.append(sid)
         mgr.cache_batch_data([0, 1], [L + 1 for L in lens])
         runner._input_ids[:2] = ids.to(DEV)
         outs.append(runner.decode(runner._input_ids[:2], 2, mgr).clone().cpu())
-        if chain:
-            assert runner._chain_ok.get(2) is True
+        if one_launch:
+            assert any(runner._qkv_attn_ok.values()), "the library refused to fuse the headline head shape"
+            torch.cuda.synchronize()
+            assert int(runner._qa_status[0]) == 0
         del runner, mgr
         torch.cuda.empty_cache()
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
