@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <numeric>
 #include <random>
+#include <string>
 #include <vector>
 
 #define CHECK(x)                                                                      \
@@ -149,6 +150,19 @@ int main(int argc, char** argv) {
         const double us = kernel_run(as, 4);
         printf("  %-58s %8.2f us  %7.1f GB/s\n", what, us, mb / us * 1e3);
     };
+    if (argc > 3 && std::string(argv[3]) == "calib") {
+        // Calibration of byte counters (rocprofv3 --pmc FETCH_SIZE -- kv_stream BS CTX calib SPLITS):
+        // launches of ONE variant - the attention kernel's own shape, 4 waves, 4 rows x 4 per stage -
+        // each of which reads exactly `mb` MB (every row of every sequence and kv head once, K and V),
+        // from pools visited in turn so that no launch finds its rows in a cache.
+        const int nsplit = argc > 4 ? atoi(argv[4]) : 1;
+        std::vector<Args> as;
+        for (int l = 0; l < layers; ++l) as.push_back(Args{k[l], v[l], table, sink, bs, hkv, ctx, pps, nsplit, 0});
+        const double us = run<4, 4>(as, 4);
+        printf("calib: stream_kernel<4,4> %d splits, %d launches, %.0f bytes per launch, %.2f us\n", nsplit,
+               (int)(5 * as.size()), mb * 1e6, us);
+        return 0;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         printf(" pass %d\n", pass);
         report("paged, 4 waves, 4 rows x 4 per stage, 1 split", run<4, 4>, 1, 0);
