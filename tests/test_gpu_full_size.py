@@ -54,7 +54,7 @@ def _build(bs, fused=True, seed=5):
     return cfg, runner, mgr, RefRunner(cpu_model, cfg.head_dim, world=1, max_blocks=max_tokens // 256), ref_cache, lens
 
 
-@pytest.mark.parametrize("bs", [1, 8])
+@pytest.mark.parametrize("bs", [1, 8, 32])   # 32: the continuous-batching configuration's batch size
 def test_llama3_8b_dimensions_decode_step(mv, bs):
     cfg, runner, mgr, ref, ref_cache, lens = _build(bs)
     sids = list(range(bs))
