@@ -41,6 +41,18 @@ FLAGS = [
 ]
 
 
+# per-source additions.  attn_prefill.hip: the pipelined attention deals its vector work out slot
+# by slot beside the MFMAs; the SLP vectoriser would gather the row-sum additions of many slots
+# into one chain of packed additions (slower beside MFMAs than the scalar form, and serial)
+FILE_FLAGS = {
+    "attn_prefill.hip": ["-fno-slp-vectorize"],
+}
+
+
+def _flags_for(source_name):
+    return FLAGS + FILE_FLAGS.get(source_name, [])
+
+
 def _hipcc():
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
@@ -68,7 +80,7 @@ def build_variant(name, defines, only=("wgemm.hip",), verbose=False):
         obj = os.path.join(OBJDIR, s.replace(".hip", ".o"))
         if s in only:
             obj = os.path.join(OBJDIR, s.replace(".hip", f".{name}.o"))
-            cmd = [hipcc] + FLAGS + [f"-D{d}" for d in defines] + ["-c", src, "-o", obj]
+            cmd = [hipcc] + _flags_for(s) + [f"-D{d}" for d in defines] + ["-c", src, "-o", obj]
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             if r.returncode != 0:
                 raise RuntimeError(r.stdout)
@@ -99,7 +111,7 @@ def build(force=False, verbose=True, jobs=None):
 
     def compile_one(pair):
         src, obj = pair
-        cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [hipcc] + _flags_for(os.path.basename(src)) + ["-c", src, "-o", obj]
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

@@ -20,6 +20,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace mv {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -47,6 +49,11 @@ static const int g_pf_waves = [] {
     const char* e = getenv("MVLLM_PREFILL_ATTN_WAVES");
     const int v = e && *e ? atoi(e) : 0;
     return v == 4 || v == 8 ? v : 0;
+}();
+// MVLLM_PREFILL_ATTN_PIPE = 0 keeps the eight-wave workgroups on the plain (un-pipelined) kernel
+static const bool g_pf_pipe = [] {
+    const char* e = getenv("MVLLM_PREFILL_ATTN_PIPE");
+    return !(e && *e == '0');
 }();
 
 // 256-row (8-wave) workgroups for long chunks (measured: 4096 tokens 202 against 220-229 us per layer
@@ -425,7 +432,429 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void paged_attn_prefill_k
     }
 }
 
+// ---- the pipelined form: 256 stacked query rows per workgroup, 32 per wave ---------------------
+// Same workgroup shape and tiles as the eight-wave form above, three differences:
+//   * both products run on v_mfma_f32_32x32x16_bf16.  S^T = K . Q^T leaves a lane (query l & 31,
+//     half h = l >> 5) 16 scores per 32-key block, keys (r & 3) + 8 (r >> 2) + 4 h for register r:
+//     a query's maximum is one exchange between lanes l and l + 32, and a 32-cycle MFMA holds the
+//     SIMD's vector issue for 8 of its cycles where the 16x16x32 form holds it for 8 of 16 - the
+//     softmax arithmetic (two thirds as many issue cycles as the MFMAs themselves) only fits beside
+//     MFMAs of the wide form.  Registers 8 s .. 8 s + 7 of a block, rounded to bf16, are the B
+//     operand of k-step s of O^T += V^T . P^T as they stand: contraction slot (h, j) is key
+//     16 s + 4 h + j for j < 4 and 16 s + 8 + 4 h + (j - 4) above, and the transposing reads of V
+//     deliver exactly those keys (two 4-key blocks 8 keys apart per lane group).
+//   * software pipeline over 32-key blocks: while the MFMAs of S(u + 1) run, the vector unit turns
+//     S(u) into P(u); while those of O += V(u)^T P(u) run, it takes the row maxima of S(u + 1).
+//     The MFMAs, the LDS reads that feed them (issued a few MFMAs ahead) and the softmax pieces are
+//     dealt out slot by slot between scheduling fences, so the order written here is the order
+//     issued - and a score pair's three stages (scale and subtract, exponential, sum and round)
+//     stand in three consecutive slots: a wave issues in order, and with the stages of one pair
+//     back to back every slot waited out the latencies of its own chain (55 cycles per slot where
+//     the MFMA takes 32).  One barrier per 64-key tile: tile step t reads K(t) (upper half),
+//     K(t + 1) (lower half) and V(t), and fills the buffers of K(t + 2) and V(t + 1), which nothing
+//     reads before that barrier - K therefore sits in a ring of three tiles, V in two.
+//   * a row's running maximum is raised (and the output accumulators rescaled, at the top of the
+//     next block step) only when some row of the wave outgrew its own by 2^kRaise, see below.
+// Rows of V are padded to a stride of 16 banks mod 64 (the transposing reads of a 32-lane half
+// touch four rows x two column groups: conflict-free), rows of K by 16 bytes as above.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// one instruction where fmaxf(fmaxf(a, b), c) is three (a canonicalising self-maximum per operand
+// that came out of an MFMA, then two maxima)
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+#ifdef MV_PFX_STAMP
+// Stamp build (tools/stamp_attn_prefill.py): shader-clock ticks at eight points of tile steps
+// kStampFrom .. + 15, for every wave of workgroup 0 (the heaviest query block).  The stamps are kept in
+// LDS and copied out at the end.
+constexpr int kStampFrom = 24;
+static __device__ unsigned long long g_pfx_stamp[8 * 16 * 8];
+#define MV_PSTAMP(slot)                                                                        \
+    do {                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+        if (blockIdx.x == 0 && lane == 0 && t >= kStampFrom && t < kStampFrom + 16)            \
+            stampL[(wid * 16 + t - kStampFrom) * 8 + (slot)] = __builtin_readcyclecounter();   \
+        __builtin_amdgcn_sched_barrier(0);                                                     \
+    } while (0)
+#else
+#define MV_PSTAMP(slot)
+#endif
+
+#ifndef MV_PFX_PF
+#define MV_PFX_PF 3
+#endif
+#ifndef MV_PFX_PFV
+#define MV_PFX_PFV 5
+#endif
+#ifndef MV_PFX_THR
+#define MV_PFX_THR 8.0f
+#endif
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs a) {
+    constexpr int NT = 512, KT = 64;
+    constexpr int KS = D / 16;          // MFMAs of one 32-key block of S^T (k-steps of 16)
+    constexpr int DB = D / 32;          // 32-row blocks of O^T
+    constexpr int NP = 2 * DB;          // MFMAs of one 32-key block of O^T (two k-steps of 16 keys)
+    constexpr int PF = MV_PFX_PF < KS ? MV_PFX_PF : KS - 1;     // K fragment reads run this many MFMAs ahead
+    constexpr int PFV = MV_PFX_PFV < NP ? MV_PFX_PFV : NP - 1;  // V fragment reads likewise
+    // A row's running maximum is raised only when some row of the wave outgrows its own by more
+    // than this many powers of two: the weights then stay below 2^kRaise instead of 1 (harmless in
+    // bf16 and fp32) and the 16 DB multiplications of the output accumulators are skipped in all
+    // but the first blocks of a sequence.  0 = raise it whenever any row's maximum rose.
+    constexpr float kRaise = MV_PFX_THR;
+    constexpr int KROW = D * 2 + 16, VROW = D * 2 + 64;
+    constexpr int VPR = D / 8, NV = KT * VPR / NT;
+    static_assert(NV == 1 || NV == 2, "one or two vectors per thread and tile");
+    __shared__ __attribute__((aligned(16))) unsigned char kL[3][KT * KROW];
+    __shared__ __attribute__((aligned(16))) unsigned char vL[2][KT * VROW];
+#ifdef MV_PFX_STAMP
+    __shared__ unsigned long long stampL[8 * 16 * 8];
+#endif
+
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lq = lane & 31, hi = lane >> 5;
+
+    const int per = a.hkv * a.B;
+    const int qb = a.nqb - 1 - (int)(blockIdx.x / per);   // heaviest query blocks first
+    const int rem = blockIdx.x % per;
+    const int kvh = rem % a.hkv, b = rem / a.hkv;
+    const int p0 = max(a.start[b], 0);
+    const int i0 = qb * a.qt;
+    const int last_key = p0 + min(i0 + a.qt, a.S) - 1;
+    const int ntiles = last_key / KT + 1;
+    // The block table does not change under the kernel: read through the constant address space its
+    // entries are scalar loads whatever else the kernel stores (a vector load of a page id would sit
+    // behind the tile requests in the in-order counter and wait for them).
+    typedef const __attribute__((address_space(4))) int32_t* const_i32_ptr;
+    const_i32_ptr bt = (const_i32_ptr)(uintptr_t)(a.block_table + (int64_t)b * a.bt_stride);
+
+    // this lane's query row
+    const int row = wid * 32 + lq;
+    const int gi = row >> a.qt_shift, pos_i = i0 + (row & (a.qt - 1));
+    const int head = kvh * a.g + min(gi, a.g - 1);
+    const int qi = gi < a.g ? pos_i : a.S;   // a head that does not exist: never stored
+    const int ic = min(pos_i, a.S - 1);
+    const int limit = p0 + ic;
+    bf16x8_t qf[KS];
+    {
+        const uint16_t* qp = a.q + ((int64_t)b * a.S + ic) * a.q_stride + (int64_t)head * D + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, ld16(qp + ks * 16));
+    }
+    int wave_min_limit = limit;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) wave_min_limit = min(wave_min_limit, __shfl_xor(wave_min_limit, o, 64));
+    wave_min_limit = __builtin_amdgcn_readfirstlane(wave_min_limit);
+    const int n_full = (wave_min_limit + 1) / 32;   // leading 32-key blocks no row of this wave has to mask
+
+    // ---- staging: thread moves vectors tid, tid + 512 of a 64 x VPR tile.  A tile's rows lie
+    // hkv * D elements apart from a base that is uniform over the workgroup (page, first row in the
+    // page, kv head): the per-lane part is 32 bits wide and almost constant - only the last tile
+    // clamps rows past the last key (finite data in place of rows never written).
+    // (Staging registers are native vectors: copies of HIP's uint4 struct between address spaces are
+    // memcpy calls to the compiler, which then kept the staging area in memory - in LDS, next to the
+    // tiles - and every request waited for its data on the spot.)
+    struct Stage {
+        u32x4_t r0, r1;
+    };
+    const int srow0 = threadIdx.x / VPR, srow1 = (threadIdx.x + NT * (NV - 1)) / VPR, sch16 = (threadIdx.x % VPR) * 16;
+    const int row_bytes = a.hkv * D * 2;
+    const unsigned page_bytes = (unsigned)a.page * (unsigned)row_bytes;   // (checked on the host: below 2^32)
+    auto page_of = [&](int t) __attribute__((always_inline)) {   // (range-checked where it is used)
+        return bt[min((min(t, ntiles - 1) * KT) >> a.page_shift, a.bt_stride - 1)];
+    };
+    // byte offset of tile t in either cache: from its page id where a page begins, 64 rows after the
+    // tile before it otherwise (two scalar additions instead of a multiplication chain per step);
+    // tiles past the last one repeat it (a harmless re-fetch that is never read)
+    auto tile_offset = [&](int t, int pg_raw, uint64_t prev) __attribute__((always_inline)) -> uint64_t {
+        if (t >= ntiles) return prev;
+        if (t > 0 && ((t * KT) & (a.page - 1)) != 0) return prev + (uint64_t)(KT * row_bytes);
+        const unsigned pg = (pg_raw >= 0 && pg_raw < a.num_pages) ? pg_raw : 0;   // unallocated entry: stay inside the cache
+        return (uint64_t)pg * page_bytes + (unsigned)(kvh * D * 2);
+    };
+    auto g_load = [&](Stage& sr, const uint16_t* cache, uint64_t toff, int t) __attribute__((always_inline)) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(cache) + toff;
+        const int last_rel = last_key - min(t, ntiles - 1) * KT;
+        sr.r0 = *reinterpret_cast<const u32x4_t*>(base + (unsigned)(min(srow0, last_rel) * row_bytes + sch16));
+        if constexpr (NV > 1)
+            sr.r1 = *reinterpret_cast<const u32x4_t*>(base + (unsigned)(min(srow1, last_rel) * row_bytes + sch16));
+    };
+    auto k_store = [&](const Stage& sr, int buf, int which) __attribute__((always_inline)) {
+        if (which == 0) *reinterpret_cast<u32x4_t*>(&kL[buf][srow0 * KROW + sch16]) = sr.r0;
+        if (NV > 1 && which == 1) *reinterpret_cast<u32x4_t*>(&kL[buf][srow1 * KROW + sch16]) = sr.r1;
+    };
+    auto v_store = [&](const Stage& sr, int buf, int which) __attribute__((always_inline)) {
+        if (which == 0) *reinterpret_cast<u32x4_t*>(&vL[buf][srow0 * VROW + sch16]) = sr.r0;
+        if (NV > 1 && which == 1) *reinterpret_cast<u32x4_t*>(&vL[buf][srow1 * VROW + sch16]) = sr.r1;
+    };
+
+    // ---- fragment reads
+    const int k_off = lq * KROW + hi * 16;
+    auto k_frag = [&](const unsigned char* kblock, int ks) __attribute__((always_inline)) {   // kblock: first row of a 32-key block
+        return __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(kblock + ks * 32 + k_off));
+    };
+    const int li = lane & 15;
+    const int tr_off = (4 * hi + (li >> 2)) * VROW + (16 * ((lane >> 4) & 1) + 4 * (li & 3)) * 2;
+    auto v_frag = [&](const unsigned char* vblock, int j) __attribute__((always_inline)) {   // MFMA j of a block: k-step j / DB, rows 32 (j % DB) of O^T
+        const unsigned char* vb = vblock + (j / DB) * 16 * VROW + (j % DB) * 64 + tr_off;
+        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4_t __attribute__((address_space(3)))*)(vb));
+        const s16x4_t up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (s16x4_t __attribute__((address_space(3)))*)(vb + 8 * VROW));
+        const s16x8_t both = {lo[0], lo[1], lo[2], lo[3], up[0], up[1], up[2], up[3]};
+        return __builtin_bit_cast(bf16x8_t, both);
+    };
+
+    f32x16_t oacc[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    float mrun = kPfNegBig, lrun0 = 0.f, lrun1 = 0.f, alpha = 1.f;
+    bool rescale = false;
+    uint32_t pw[8];   // P of the current block rounded to bf16, two scores per word
+
+    // A score pair (registers 2 pr, 2 pr + 1 of the block) goes through three stages, one slot apart
+    float fa[8][2], eb[8][2];
+    auto stage_a = [&](const f32x16_t& sc, int pr) __attribute__((always_inline)) {
+        fa[pr][0] = __builtin_fmaf(sc[2 * pr], a.scale_log2, -mrun);
+        fa[pr][1] = __builtin_fmaf(sc[2 * pr + 1], a.scale_log2, -mrun);
+    };
+    auto stage_b = [&](int pr) __attribute__((always_inline)) {
+        eb[pr][0] = __builtin_amdgcn_exp2f(fa[pr][0]);
+        eb[pr][1] = __builtin_amdgcn_exp2f(fa[pr][1]);
+    };
+    auto stage_c = [&](int pr) __attribute__((always_inline)) {
+        lrun0 += eb[pr][0];
+        lrun1 += eb[pr][1];
+        pw[pr] = pack_bf16x2(eb[pr][0], eb[pr][1]);
+    };
+    // the stages that stand at pipeline position q (0 .. KS + NP - 1 over the two stretches of a
+    // block step): pair pr enters at position pr KS / 8
+    auto softmax_slot = [&](const f32x16_t& sc, int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+            const int q0 = pr * KS / 8;
+            if (q == q0 + 2) stage_c(pr);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+            const int q0 = pr * KS / 8;
+            if (q == q0 + 1) stage_b(pr);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {
+            const int q0 = pr * KS / 8;
+            if (q == q0) stage_a(sc, pr);
+        }
+    };
+    auto p_frag = [&](int s) __attribute__((always_inline)) {   // B operand of k-step s (0, 1) of the block's share of O^T
+        const uint4 w = make_uint4(pw[4 * s], pw[4 * s + 1], pw[4 * s + 2], pw[4 * s + 3]);
+        return __builtin_bit_cast(bf16x8_t, w);
+    };
+    // Row maximum of a block in four pieces over two accumulators: registers 0-5, 6-9, 10-13, 14-15.
+    // lim_rel = this row's last key relative to the block's first, less 4 hi; masked: keys past it
+    // are set to the floor, in the scores too.
+    float m2[2];
+    auto max_piece = [&](f32x16_t& sn, int mi, int lim_rel, auto masked) __attribute__((always_inline)) {
+        constexpr int first[5] = {0, 6, 10, 14, 16};
+        if constexpr (decltype(masked)::value) {
+#pragma unroll
+            for (int r = first[mi]; r < first[mi + 1]; ++r)
+                if ((r & 3) + 8 * (r >> 2) > lim_rel) sn[r] = kPfNegBig;
+        }
+        if (mi == 0) {
+            m2[0] = max3_f32(sn[0], sn[1], sn[2]);
+            m2[1] = max3_f32(sn[3], sn[4], sn[5]);
+        } else if (mi == 1) {
+            m2[0] = max3_f32(m2[0], sn[6], sn[7]);
+            m2[1] = max3_f32(m2[1], sn[8], sn[9]);
+        } else if (mi == 2) {
+            m2[0] = max3_f32(m2[0], sn[10], sn[11]);
+            m2[1] = max3_f32(m2[1], sn[12], sn[13]);
+        } else {
+            m2[0] = max3_f32(m2[0], sn[14], sn[15]);
+        }
+    };
+    // after the four pieces: the row's maximum over both lane halves, the new running maximum and
+    // the factor the accumulators owe it
+    auto max_finish = [&]() __attribute__((always_inline)) {
+        float mloc = fmaxf(m2[0], m2[1]) * a.scale_log2;
+        const unsigned u = __float_as_uint(mloc);
+        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        rescale = __builtin_amdgcn_ballot_w64(mloc > mrun + kRaise) != 0;
+        if (rescale) {
+            const float mnew = fmaxf(mrun, mloc);
+            alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+            mrun = mnew;
+        }
+    };
+    auto apply_rescale = [&]() __attribute__((always_inline)) {
+        if (rescale) {
+            lrun0 *= alpha;
+            lrun1 *= alpha;
+#pragma unroll
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        }
+    };
+
+    // One block step: scores `sc` of block u (maxima taken) -> P(u) -> O from the V rows at
+    // `vblock`; scores of block u + 1 (K rows at `kblock`, first key `next_key0`) -> `sn`.
+    // `tail(j)` is called in slot j of the second stretch (the tile step's LDS stores ride there).
+    auto block_step = [&](const f32x16_t& sc, f32x16_t& sn, const unsigned char* kblock, const unsigned char* vblock,
+                          int next_key0, auto has_next, auto mask_next, int t, int slot0, auto&& tail)
+                          __attribute__((always_inline)) {
+        constexpr bool kNext = decltype(has_next)::value;
+        apply_rescale();
+        MV_PSTAMP(slot0);
+        // stretch 1: S(u + 1) on the matrix pipe
+        bf16x8_t kf[KS];
+        if constexpr (kNext) {
+#pragma unroll
+            for (int i = 0; i < PF; ++i) kf[i] = k_frag(kblock, i);
+        }
+#pragma unroll
+        for (int i = 0; i < KS; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kNext) {
+                if (i + PF < KS) kf[i + PF] = k_frag(kblock, i + PF);
+                const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i], i == 0 ? zero : sn, 0, 0, 0);
+            }
+            softmax_slot(sc, i);
+        }
+        MV_PSTAMP(slot0 + 1);
+        // stretch 2: O += V(u)^T P(u); the tail of the softmax pipeline in its first slots (the
+        // second k-step needs all of P), the maxima of S(u + 1) in its second half
+        const int lim_rel = limit - next_key0 - 4 * hi;
+        bf16x8_t vf[NP];
+#pragma unroll
+        for (int j = 0; j < PFV; ++j) vf[j] = v_frag(vblock, j);
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + PFV < NP) vf[j + PFV] = v_frag(vblock, j + PFV);
+            oacc[j % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], p_frag(j / DB), oacc[j % DB], 0, 0, 0);
+            softmax_slot(sc, KS + j);
+            if constexpr (kNext) {
+                if (j >= DB) {
+#pragma unroll
+                    for (int mi = (j - DB) * 4 / DB; mi < (j - DB + 1) * 4 / DB; ++mi) max_piece(sn, mi, lim_rel, mask_next);
+                }
+            }
+            tail(j);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        MV_PSTAMP(slot0 + 2);
+        if constexpr (kNext) max_finish();
+    };
+    auto no_tail = [](int) __attribute__((always_inline)) {};
+
+    // ---- prologue: K(0), V(0), K(1) staged; S of block 0 and its maxima
+    Stage sr, sv;
+    int pg3 = page_of(3);
+    uint64_t off1, off2;   // byte offsets of tiles t + 1 and t + 2
+    {
+        const uint64_t off0 = tile_offset(0, page_of(0), 0);
+        off1 = tile_offset(1, page_of(1), off0);
+        off2 = tile_offset(2, page_of(2), off1);
+        g_load(sr, a.k_cache, off0, 0);
+        g_load(sv, a.v_cache, off0, 0);
+        k_store(sr, 0, 0);
+        k_store(sr, 0, 1);
+        v_store(sv, 0, 0);
+        v_store(sv, 0, 1);
+        g_load(sr, a.k_cache, off1, 1);
+        k_store(sr, 1, 0);
+        k_store(sr, 1, 1);
+    }
+    __syncthreads();
+    f32x16_t s0, s1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_frag(&kL[0][0], i), qf[i], s0, 0, 0, 0);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) max_piece(s0, mi, limit - 4 * hi, std::true_type{});
+    max_finish();
+
+    // One tile step: blocks 2 t (scores in s0) and 2 t + 1; leaves the scores of block 2 t + 2 in s0.
+    int kc = 0, kn = 1, kw = 2;   // ring slots of K(t), K(t + 1), K(t + 2)
+    auto tile_step = [&](int t, auto masks) __attribute__((always_inline)) {
+        const unsigned char* kcur = &kL[kc][0];
+        const unsigned char* knext = &kL[kn][0];
+        const unsigned char* vcur = &vL[t & 1][0];
+        MV_PSTAMP(0);
+        // K(t + 2) and V(t + 1) requested now; they are written to LDS beside the last MFMAs of the
+        // step, a whole step for the requests to land
+        g_load(sr, a.k_cache, off2, t + 2);
+        g_load(sv, a.v_cache, off1, t + 1);
+        off1 = off2;
+        off2 = tile_offset(t + 3, pg3, off2);
+        pg3 = page_of(t + 4);   // its scalar load has a whole step to land
+        block_step(s0, s1, kcur + 32 * KROW, vcur, t * KT + 32, std::true_type{}, masks, t, 1, no_tail);
+        const int kdst = kw, vdst = (t + 1) & 1;
+        block_step(s1, s0, knext, vcur + 32 * VROW, (t + 1) * KT, std::true_type{}, masks, t, 4,
+                   [&](int j) __attribute__((always_inline)) {
+                       // four (two) stores over the last slots of the step
+                       const int k = j - (NP - 2 * NV);
+                       if (k >= 0 && k < NV) k_store(sr, kdst, k);
+                       if (k >= NV && k < 2 * NV) v_store(sv, vdst, k - NV);
+                   });
+        const int k_old = kc;
+        kc = kn;
+        kn = kw;
+        kw = k_old;
+        __syncthreads();
+        MV_PSTAMP(7);
+    };
+    int t = 0;
+    // (whether a block needs the mask is uniform over the wave; once one does, all later ones do)
+    for (; t + 1 < ntiles && 2 * t + 2 < n_full; ++t) tile_step(t, std::false_type{});
+    for (; t + 1 < ntiles; ++t) tile_step(t, std::true_type{});
+    // the last tile: its second block has no successor
+    block_step(s0, s1, &kL[kc][0] + 32 * KROW, &vL[t & 1][0], t * KT + 32, std::true_type{}, std::true_type{}, 1000, 1,
+               no_tail);
+    block_step(s1, s0, &kL[kc][0], &vL[t & 1][0] + 32 * VROW, 0, std::false_type{}, std::false_type{}, 1000, 4, no_tail);
+
+#ifdef MV_PFX_STAMP
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 8 * 16 * 8; i += NT) g_pfx_stamp[i] = stampL[i];
+#endif
+    // oacc[db][r] = O^T[d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi][this lane's query]
+    float l = lrun0 + lrun1;
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (qi < a.S) {
+        uint16_t* op = a.out + ((int64_t)b * a.S + qi) * a.out_stride + (int64_t)head * D + 4 * hi;
+#pragma unroll
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                uint2 w;
+                w.x = pack_bf16x2(oacc[db][4 * rq] * inv, oacc[db][4 * rq + 1] * inv);
+                w.y = pack_bf16x2(oacc[db][4 * rq + 2] * inv, oacc[db][4 * rq + 3] * inv);
+                *reinterpret_cast<uint2*>(op + db * 32 + rq * 8) = w;
+            }
+    }
+}
+
 }  // namespace mv
+
+#ifdef MV_PFX_STAMP
+extern "C" int mv_debug_read_pfx_stamps(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_pfx_stamp), bytes) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" {
 
@@ -547,7 +976,13 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
     const int64_t grid = (int64_t)a.nqb * hkv * bs;
     if (grid > 0x7fffffffLL) return MV_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    if (d == 128 && eight)
+    // the pipelined form keeps a page's byte size in 32 bits
+    const bool pipe = eight && g_pf_pipe && (int64_t)page * hkv * d * 2 < (1LL << 32);
+    if (d == 128 && pipe)
+        hipLaunchKernelGGL((paged_attn_prefill_pipe_kernel<128>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else if (pipe)
+        hipLaunchKernelGGL((paged_attn_prefill_pipe_kernel<64>), dim3((unsigned)grid), dim3(512), 0, st, a);
+    else if (d == 128 && eight)
         hipLaunchKernelGGL((paged_attn_prefill_kernel<128, 8>), dim3((unsigned)grid), dim3(512), 0, st, a);
     else if (d == 128)
         hipLaunchKernelGGL((paged_attn_prefill_kernel<128, 4>), dim3((unsigned)grid), dim3(256), 0, st, a);

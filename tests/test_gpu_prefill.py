@@ -126,6 +126,39 @@ def test_prefill_attention_long_chunks_take_256_row_workgroups(mv):
     assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst excess {(err - tol).max().item():.3e}"
 
 
+@pytest.mark.parametrize("D,Hq,Hkv,S,starts", [
+    (128, 8, 2, 2048, [0, 256, 5, 300]),                    # four query heads per kv head (the 8B ratio)
+    (128, 4, 4, 2048, [0, 7, 64, 100, 300, 1, 31, 255]),    # one: 256 positions per workgroup
+    (128, 16, 2, 2048, [0, 33]),                            # eight: 32 positions per workgroup
+    (128, 6, 2, 2048, [3, 0, 129, 64]),                     # three, padded to four in the row stack
+    (128, 8, 2, 2100, [0, 1, 63, 64, 65, 200, 256]),        # a last query block that is partly empty
+    (64, 4, 2, 2048, [0, 17, 250, 64, 1, 0, 0, 300]),       # heads of 64
+])
+def test_prefill_attention_pipelined_form_vs_oracle(mv, D, Hq, Hkv, S, starts):
+    """The software-pipelined eight-wave kernel (long chunks) at every stack shape it has: exact
+    append, output within the same bounds as the plain kernel above.  The first tiles of a sequence
+    that starts at 0, the masked tiles on the diagonal (starts that are not multiples of 32 or 64
+    put the mask boundary inside a block) and rows past the chunk are all in these cases."""
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.core.paged_attention import flash_attn_with_kvcache
+
+    B = len(starts)
+    assert nv.lib().mv_paged_attn_prefill_form(B, S, Hq, Hkv) == 8, "meant to take the 8-wave form"
+    need = sum((st + S + 255) // 256 for st in starts)
+    q, k, v, kc, vc, bt, st = _paged_case(B, S, Hq, Hkv, D, starts, seed=S + D + Hq, n_pages=need + 3,
+                                          max_blocks=(max(starts) + S + 255) // 256 + 1)
+    kc1, vc1 = kc.clone(), vc.clone()
+    exact, bound = flash_attn_with_kvcache_ref(q, kc1, vc1, k, v, None, None, st, bt, causal=True,
+                                               p_bf16=False, return_p_bound=True)
+    kcd, vcd = kc.to(DEV), vc.to(DEV)
+    got = flash_attn_with_kvcache(q.to(DEV), kcd, vcd, k=k.to(DEV), v=v.to(DEV),
+                                  cache_seqlens=st.to(DEV), block_table=bt.to(DEV), causal=True).cpu()
+    assert torch.equal(kcd.cpu(), kc1) and torch.equal(vcd.cpu(), vc1)
+    err = (got.float() - exact.float()).abs()
+    tol = 1e-3 + 2 ** -7 * exact.float().abs() + bound
+    assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst excess {(err - tol).max().item():.3e}"
+
+
 def _build(mv, shape, qkv_bias=False, n_blocks=24, max_bs=4, p_bf16=False):
     from micro_vllm_amd.core.cache_manager import KVCacheManager
     from micro_vllm_amd.core.layer.model_graph import ModelGraphRunner
