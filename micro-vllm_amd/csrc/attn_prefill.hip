@@ -488,7 +488,7 @@ static __device__ unsigned long long g_pfx_stamp[8 * 16 * 8];
 #define MV_PFX_PF 3
 #endif
 #ifndef MV_PFX_PFV
-#define MV_PFX_PFV 5
+#define MV_PFX_PFV 7
 #endif
 #ifndef MV_PFX_THR
 #define MV_PFX_THR 8.0f
@@ -635,23 +635,19 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
         pw[pr] = pack_bf16x2(eb[pr][0], eb[pr][1]);
     };
     // the stages that stand at pipeline position q (0 .. KS + NP - 1 over the two stretches of a
-    // block step): pair pr enters at position pr KS / 8
+    // block step): pair pr enters at kEnter[pr], pairs 0-3 early enough to be words of P when the
+    // second stretch begins
     auto softmax_slot = [&](const f32x16_t& sc, int q) __attribute__((always_inline)) {
+        constexpr int kEnter128[8] = {1, 2, 3, 4, 5, 6, 7, 8}, kEnter64[8] = {1, 1, 1, 1, 2, 2, 3, 3};
 #pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {
-            const int q0 = pr * KS / 8;
-            if (q == q0 + 2) stage_c(pr);
-        }
+        for (int pr = 0; pr < 8; ++pr)
+            if (q == (D == 128 ? kEnter128[pr] : kEnter64[pr]) + 2) stage_c(pr);
 #pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {
-            const int q0 = pr * KS / 8;
-            if (q == q0 + 1) stage_b(pr);
-        }
+        for (int pr = 0; pr < 8; ++pr)
+            if (q == (D == 128 ? kEnter128[pr] : kEnter64[pr]) + 1) stage_b(pr);
 #pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {
-            const int q0 = pr * KS / 8;
-            if (q == q0) stage_a(sc, pr);
-        }
+        for (int pr = 0; pr < 8; ++pr)
+            if (q == (D == 128 ? kEnter128[pr] : kEnter64[pr])) stage_a(sc, pr);
     };
     auto p_frag = [&](int s) __attribute__((always_inline)) {   // B operand of k-step s (0, 1) of the block's share of O^T
         const uint4 w = make_uint4(pw[4 * s], pw[4 * s + 1], pw[4 * s + 2], pw[4 * s + 3]);
@@ -706,42 +702,50 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
         }
     };
 
-    // One block step: scores `sc` of block u (maxima taken) -> P(u) -> O from the V rows at
-    // `vblock`; scores of block u + 1 (K rows at `kblock`, first key `next_key0`) -> `sn`.
-    // `tail(j)` is called in slot j of the second stretch (the tile step's LDS stores ride there).
+    // One block step: scores `sc` of block u (maximum pieces taken) -> P(u) -> O from the V rows at
+    // `vblock`; scores of block u + 1 (K rows at `kblock`, first key `next_key0`) -> `sn`.  The LDS
+    // reads of a stretch's first MFMAs are issued beside the last MFMAs of the stretch before it
+    // (their latency would stand exposed at every stretch start): `kpre` holds the first PF K
+    // fragments of this step, read during the step before, and is refilled from `kblock_after` (the
+    // K rows of the step that follows) if `has_after`.  `tail(j)` is called in slot j of the
+    // second stretch, `hook(q)` in every slot q = 0 .. KS + NP - 1 of the step (the tile step's
+    // requests and LDS stores ride there).
+    bf16x8_t kpre[PF];
     auto block_step = [&](const f32x16_t& sc, f32x16_t& sn, const unsigned char* kblock, const unsigned char* vblock,
-                          int next_key0, auto has_next, auto mask_next, int t, int slot0, auto&& tail)
-                          __attribute__((always_inline)) {
-        constexpr bool kNext = decltype(has_next)::value;
+                          const unsigned char* kblock_after, int next_key0, auto has_next, auto has_after,
+                          auto mask_next, int t, int slot0, auto&& hook) __attribute__((always_inline)) {
+        constexpr bool kNext = decltype(has_next)::value, kAfter = decltype(has_after)::value;
+        max_finish();
         apply_rescale();
         MV_PSTAMP(slot0);
-        // stretch 1: S(u + 1) on the matrix pipe
-        bf16x8_t kf[KS];
-        if constexpr (kNext) {
-#pragma unroll
-            for (int i = 0; i < PF; ++i) kf[i] = k_frag(kblock, i);
-        }
+        // stretch 1: S(u + 1) on the matrix pipe, the exponentials of S(u) beside it.  (The end of the
+        // row maximum and the rescale placed beside the first MFMA instead of in front of the
+        // stretch measured 2 % slower.)
+        bf16x8_t kf[KS], vf[NP];
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (kNext) {
+                if (i < PF) kf[i] = kpre[i];
                 if (i + PF < KS) kf[i + PF] = k_frag(kblock, i + PF);
                 const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 sn = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i], i == 0 ? zero : sn, 0, 0, 0);
             }
+            if (i + PFV >= KS) vf[i + PFV - KS] = v_frag(vblock, i + PFV - KS);
             softmax_slot(sc, i);
+            hook(i);
         }
         MV_PSTAMP(slot0 + 1);
         // stretch 2: O += V(u)^T P(u); the tail of the softmax pipeline in its first slots (the
-        // second k-step needs all of P), the maxima of S(u + 1) in its second half
+        // second k-step needs all of P), the maximum pieces of S(u + 1) in its second half
         const int lim_rel = limit - next_key0 - 4 * hi;
-        bf16x8_t vf[NP];
-#pragma unroll
-        for (int j = 0; j < PFV; ++j) vf[j] = v_frag(vblock, j);
 #pragma unroll
         for (int j = 0; j < NP; ++j) {
             __builtin_amdgcn_sched_barrier(0);
             if (j + PFV < NP) vf[j + PFV] = v_frag(vblock, j + PFV);
+            if constexpr (kAfter) {
+                if (j + PF >= NP) kpre[j + PF - NP] = k_frag(kblock_after, j + PF - NP);
+            }
             oacc[j % DB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[j], p_frag(j / DB), oacc[j % DB], 0, 0, 0);
             softmax_slot(sc, KS + j);
             if constexpr (kNext) {
@@ -750,13 +754,12 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
                     for (int mi = (j - DB) * 4 / DB; mi < (j - DB + 1) * 4 / DB; ++mi) max_piece(sn, mi, lim_rel, mask_next);
                 }
             }
-            tail(j);
+            hook(KS + j);
         }
         __builtin_amdgcn_sched_barrier(0);
         MV_PSTAMP(slot0 + 2);
-        if constexpr (kNext) max_finish();
     };
-    auto no_tail = [](int) __attribute__((always_inline)) {};
+    auto no_hook = [](int) __attribute__((always_inline)) {};
 
     // ---- prologue: K(0), V(0), K(1) staged; S of block 0 and its maxima
     Stage sr, sv;
@@ -766,15 +769,16 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
         const uint64_t off0 = tile_offset(0, page_of(0), 0);
         off1 = tile_offset(1, page_of(1), off0);
         off2 = tile_offset(2, page_of(2), off1);
+        Stage s2;   // all three tiles requested before the first is waited for
         g_load(sr, a.k_cache, off0, 0);
         g_load(sv, a.v_cache, off0, 0);
+        g_load(s2, a.k_cache, off1, 1);
         k_store(sr, 0, 0);
         k_store(sr, 0, 1);
         v_store(sv, 0, 0);
         v_store(sv, 0, 1);
-        g_load(sr, a.k_cache, off1, 1);
-        k_store(sr, 1, 0);
-        k_store(sr, 1, 1);
+        k_store(s2, 1, 0);
+        k_store(s2, 1, 1);
     }
     __syncthreads();
     f32x16_t s0, s1;
@@ -784,8 +788,12 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
     for (int i = 0; i < KS; ++i) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k_frag(&kL[0][0], i), qf[i], s0, 0, 0, 0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) max_piece(s0, mi, limit - 4 * hi, std::true_type{});
-    max_finish();
+#pragma unroll
+    for (int i = 0; i < PF; ++i) kpre[i] = k_frag(&kL[0][0] + 32 * KROW, i);
 
+    // the second-dispatched half of the workgroup loses every arbitration against the first on
+    // its SIMD (age); one static priority step evens that out (about 1 %)
+    if (wid >= 4) __builtin_amdgcn_s_setprio(1);
     // One tile step: blocks 2 t (scores in s0) and 2 t + 1; leaves the scores of block 2 t + 2 in s0.
     int kc = 0, kn = 1, kw = 2;   // ring slots of K(t), K(t + 1), K(t + 2)
     auto tile_step = [&](int t, auto masks) __attribute__((always_inline)) {
@@ -794,18 +802,23 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
         const unsigned char* vcur = &vL[t & 1][0];
         MV_PSTAMP(0);
         // K(t + 2) and V(t + 1) requested now; they are written to LDS beside the last MFMAs of the
-        // step, a whole step for the requests to land
+        // step, a whole step for the requests to land.  (Dealt out over the slots of the first block
+        // step - wave w in slot w, so that the CU's address path, 16 cycles per 1-KiB request, never
+        // has a queue - the uniform branches around them broke up the slots' instruction order and
+        // the step took 10 % longer.)
         g_load(sr, a.k_cache, off2, t + 2);
         g_load(sv, a.v_cache, off1, t + 1);
         off1 = off2;
         off2 = tile_offset(t + 3, pg3, off2);
         pg3 = page_of(t + 4);   // its scalar load has a whole step to land
-        block_step(s0, s1, kcur + 32 * KROW, vcur, t * KT + 32, std::true_type{}, masks, t, 1, no_tail);
+        block_step(s0, s1, kcur + 32 * KROW, vcur, knext, t * KT + 32, std::true_type{}, std::true_type{}, masks, t, 1,
+                   no_hook);
         const int kdst = kw, vdst = (t + 1) & 1;
-        block_step(s1, s0, knext, vcur + 32 * VROW, (t + 1) * KT, std::true_type{}, masks, t, 4,
-                   [&](int j) __attribute__((always_inline)) {
+        block_step(s1, s0, knext, vcur + 32 * VROW, knext + 32 * KROW, (t + 1) * KT, std::true_type{}, std::true_type{},
+                   masks, t, 4, [&](int q) __attribute__((always_inline)) {
                        // four (two) stores over the last slots of the step
-                       const int k = j - (NP - 2 * NV);
+                       // (behind the last MFMA, in front of the barrier, they cost 3 % more)
+                       const int k = q - (KS + NP - 2 * NV);
                        if (k >= 0 && k < NV) k_store(sr, kdst, k);
                        if (k >= NV && k < 2 * NV) v_store(sv, vdst, k - NV);
                    });
@@ -821,9 +834,10 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
     for (; t + 1 < ntiles && 2 * t + 2 < n_full; ++t) tile_step(t, std::false_type{});
     for (; t + 1 < ntiles; ++t) tile_step(t, std::true_type{});
     // the last tile: its second block has no successor
-    block_step(s0, s1, &kL[kc][0] + 32 * KROW, &vL[t & 1][0], t * KT + 32, std::true_type{}, std::true_type{}, 1000, 1,
-               no_tail);
-    block_step(s1, s0, &kL[kc][0], &vL[t & 1][0] + 32 * VROW, 0, std::false_type{}, std::false_type{}, 1000, 4, no_tail);
+    block_step(s0, s1, &kL[kc][0] + 32 * KROW, &vL[t & 1][0], nullptr, t * KT + 32, std::true_type{}, std::false_type{},
+               std::true_type{}, 1000, 1, no_hook);
+    block_step(s1, s0, &kL[kc][0], &vL[t & 1][0] + 32 * VROW, nullptr, 0, std::false_type{}, std::false_type{},
+               std::false_type{}, 1000, 4, no_hook);
 
 #ifdef MV_PFX_STAMP
     __syncthreads();
@@ -834,18 +848,22 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
     float l = lrun0 + lrun1;
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
-    if (qi < a.S) {
-        uint16_t* op = a.out + ((int64_t)b * a.S + qi) * a.out_stride + (int64_t)head * D + 4 * hi;
+    // A query's 8 output columns 8 k .. 8 k + 7 are split between its two lanes (4 each).  One
+    // v_permlane32_swap per register pair of two neighbouring column groups leaves the lower lane
+    // all 8 columns of group k and the upper lane those of group k + 1: 16-byte stores, half as many.
+    uint16_t* op = a.out + ((int64_t)b * a.S + min(qi, a.S - 1)) * a.out_stride + (int64_t)head * D + 8 * hi;
 #pragma unroll
-        for (int db = 0; db < DB; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                uint2 w;
-                w.x = pack_bf16x2(oacc[db][4 * rq] * inv, oacc[db][4 * rq + 1] * inv);
-                w.y = pack_bf16x2(oacc[db][4 * rq + 2] * inv, oacc[db][4 * rq + 3] * inv);
-                *reinterpret_cast<uint2*>(op + db * 32 + rq * 8) = w;
-            }
-    }
+        for (int rq = 0; rq < 4; rq += 2) {
+            uint32_t ax = pack_bf16x2(oacc[db][4 * rq] * inv, oacc[db][4 * rq + 1] * inv);
+            uint32_t ay = pack_bf16x2(oacc[db][4 * rq + 2] * inv, oacc[db][4 * rq + 3] * inv);
+            uint32_t bx = pack_bf16x2(oacc[db][4 * rq + 4] * inv, oacc[db][4 * rq + 5] * inv);
+            uint32_t by = pack_bf16x2(oacc[db][4 * rq + 6] * inv, oacc[db][4 * rq + 7] * inv);
+            const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            if (qi < a.S) *reinterpret_cast<uint4*>(op + db * 32 + rq * 8) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+        }
 }
 
 }  // namespace mv
@@ -976,8 +994,8 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
     const int64_t grid = (int64_t)a.nqb * hkv * bs;
     if (grid > 0x7fffffffLL) return MV_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    // the pipelined form keeps a page's byte size in 32 bits
-    const bool pipe = eight && g_pf_pipe && (int64_t)page * hkv * d * 2 < (1LL << 32);
+    // the pipelined form keeps a page's byte size in 32 bits and stores 16 bytes at a time
+    const bool pipe = eight && g_pf_pipe && (int64_t)page * hkv * d * 2 < (1LL << 32) && (out_stride % 8) == 0;
     if (d == 128 && pipe)
         hipLaunchKernelGGL((paged_attn_prefill_pipe_kernel<128>), dim3((unsigned)grid), dim3(512), 0, st, a);
     else if (pipe)
