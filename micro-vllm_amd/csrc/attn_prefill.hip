@@ -473,6 +473,8 @@ __device__ __forceinline__ float max3_f32(float a, float b, float c) {
 // LDS and copied out at the end.
 constexpr int kStampFrom = 24;
 static __device__ unsigned long long g_pfx_stamp[8 * 16 * 8];
+// per workgroup: start and end on the constant 100 MHz counter, and the hardware id words
+static __device__ unsigned long long g_pfx_wg[1024 * 3];
 #define MV_PSTAMP(slot)                                                                        \
     do {                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                     \
@@ -519,6 +521,15 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lq = lane & 31, hi = lane >> 5;
+#ifdef MV_PFX_STAMP
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {
+        g_pfx_wg[blockIdx.x * 3] = wall_clock64();
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_pfx_wg[blockIdx.x * 3 + 2] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
 
     const int per = a.hkv * a.B;
     const int qb = a.nqb - 1 - (int)(blockIdx.x / per);   // heaviest query blocks first
@@ -720,7 +731,8 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
         MV_PSTAMP(slot0);
         // stretch 1: S(u + 1) on the matrix pipe, the exponentials of S(u) beside it.  (The end of the
         // row maximum and the rescale placed beside the first MFMA instead of in front of the
-        // stretch measured 2 % slower.)
+        // stretch measured 2 % slower; cut into four branch-free parts over the last slots of the
+        // second stretch, no faster either.)
         bf16x8_t kf[KS], vf[NP];
 #pragma unroll
         for (int i = 0; i < KS; ++i) {
@@ -843,6 +855,7 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
     __syncthreads();
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < 8 * 16 * 8; i += NT) g_pfx_stamp[i] = stampL[i];
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_pfx_wg[blockIdx.x * 3 + 1] = wall_clock64();
 #endif
     // oacc[db][r] = O^T[d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi][this lane's query]
     float l = lrun0 + lrun1;
@@ -871,6 +884,9 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
 #ifdef MV_PFX_STAMP
 extern "C" int mv_debug_read_pfx_stamps(void* dst, size_t bytes) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_pfx_stamp), bytes) == hipSuccess ? 0 : -3;
+}
+extern "C" int mv_debug_read_pfx_workgroups(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_pfx_wg), bytes) == hipSuccess ? 0 : -3;
 }
 #endif
 
