@@ -43,7 +43,7 @@ __device__ __forceinline__ float max_over_lane_quarters(float v) {
     const auto b = __builtin_amdgcn_permlane32_swap(w, w, false, false);
     return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
-constexpr int kPfWideFrom = 2048;   // chunk length from which 8-wave workgroups are taken
+constexpr int kPfWideFrom = 512;   // chunk length from which 8-wave workgroups are taken
 // waves per workgroup of the attention kernel forced by MVLLM_PREFILL_ATTN_WAVES (4 or 8; read once)
 static const int g_pf_waves = [] {
     const char* e = getenv("MVLLM_PREFILL_ATTN_WAVES");
@@ -55,22 +55,32 @@ static const bool g_pf_pipe = [] {
     const char* e = getenv("MVLLM_PREFILL_ATTN_PIPE");
     return !(e && *e == '0');
 }();
+// MVLLM_PREFILL_ATTN_RAISE = x (powers of two, 0 .. 16; default 0): the pipelined kernel raises a row's
+// running maximum only when some row of the wave outgrew its own by more than 2^x.  0 is the exact
+// running maximum of the flash-attn package (the largest weight of a row is then exactly 1 when it
+// is rounded to bf16).  8 skips nearly every rescale of the output accumulators - 4096 tokens of the
+// 8B shape 152 us per layer against 174 - at 12 % more mean error against an fp32 softmax (4.4e-4
+// against 3.9e-4 on outputs of mean magnitude 0.22): a lagging maximum leaves the largest weight
+// above 1 and inexact in bf16.
+static const float g_pf_raise = [] {
+    const char* e = getenv("MVLLM_PREFILL_ATTN_RAISE");
+    const float v = e && *e ? (float)atof(e) : 0.0f;
+    return v >= 0.0f && v <= 16.0f ? v : 0.0f;
+}();
 
-// 256-row (8-wave) workgroups for long chunks (measured: 4096 tokens 202 against 220-229 us per layer
-// of the 8B shape, 8 x 1024 tokens 126 against 121) that fill their last round of one workgroup per
-// CU to nine tenths (3072 tokens: 384 workgroups on 256 CUs, 133 against 121 us)
 static int pf_group_slots(int g) {   // query heads per kv head, rounded up to a power of two
     int gp = 1;
     while (gp < g) gp <<= 1;
     return gp;
 }
 
+// 256-row (8-wave) workgroups from 512 tokens a chunk: the pipelined kernel they run is ahead of the
+// 128-row kernel at every shape measured from there (8B head shape, tools/sweep_prefill_attn_forms.sh:
+// 8 x 512 tokens 36 against 44 us, 4 x 1024 51 against 68, 2048 67 against 76 - half the CUs idle - ,
+// 3072 103 against 122, 4096 159 against 220) and level with it below (256 tokens: 14.6 against 13.2).
 static bool pf_eight_waves(int bs, int seq, int hkv, int g) {
     if (g_pf_waves) return g_pf_waves == 8;
-    const int qt8 = 256 / pf_group_slots(g);
-    const int64_t grid8 = (int64_t)((seq + qt8 - 1) / qt8) * hkv * bs;
-    const int64_t rounds8 = (grid8 + num_cus() - 1) / num_cus();
-    return seq >= kPfWideFrom && grid8 * 10 >= rounds8 * num_cus() * 9;
+    return seq >= kPfWideFrom;
 }
 
 // ------------------------------------------------------------------ rotate + store
@@ -186,6 +196,7 @@ struct PfArgs {
     int nqb;
     int page_shift, num_pages, page;
     float scale_log2;
+    float raise;            // pipelined kernel: powers of two a row's maximum may lag (0 = never)
 };
 
 // NW waves per workgroup = 32 NW stacked query rows against every staged K/V tile: 4 (128 rows, two
@@ -453,8 +464,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void paged_attn_prefill_k
 //     the MFMA takes 32).  One barrier per 64-key tile: tile step t reads K(t) (upper half),
 //     K(t + 1) (lower half) and V(t), and fills the buffers of K(t + 2) and V(t + 1), which nothing
 //     reads before that barrier - K therefore sits in a ring of three tiles, V in two.
-//   * a row's running maximum is raised (and the output accumulators rescaled, at the top of the
-//     next block step) only when some row of the wave outgrew its own by 2^kRaise, see below.
+//   * the rescale of the output accumulators (taken when some row's maximum rose - or, if the
+//     caller allows the maximum to lag, rose by more than that) happens at the top of the next
+//     block step, off the MFMA-paired stretches.
 // Rows of V are padded to a stride of 16 banks mod 64 (the transposing reads of a 32-lane half
 // touch four rows x two column groups: conflict-free), rows of K by 16 bytes as above.
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -492,9 +504,6 @@ static __device__ unsigned long long g_pfx_wg[1024 * 3];
 #ifndef MV_PFX_PFV
 #define MV_PFX_PFV 7
 #endif
-#ifndef MV_PFX_THR
-#define MV_PFX_THR 8.0f
-#endif
 
 template <int D>
 __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs a) {
@@ -505,10 +514,11 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
     constexpr int PF = MV_PFX_PF < KS ? MV_PFX_PF : KS - 1;     // K fragment reads run this many MFMAs ahead
     constexpr int PFV = MV_PFX_PFV < NP ? MV_PFX_PFV : NP - 1;  // V fragment reads likewise
     // A row's running maximum is raised only when some row of the wave outgrows its own by more
-    // than this many powers of two: the weights then stay below 2^kRaise instead of 1 (harmless in
-    // bf16 and fp32) and the 16 DB multiplications of the output accumulators are skipped in all
-    // but the first blocks of a sequence.  0 = raise it whenever any row's maximum rose.
-    constexpr float kRaise = MV_PFX_THR;
+    // than this many powers of two (the caller's choice, 0 = whenever any row's maximum rose: the
+    // exact running maximum).  Above 0 the weights stay below 2^kRaise instead of 1 and the 16 DB
+    // multiplications of the output accumulators are skipped in all but the first blocks of a
+    // sequence.
+    const float kRaise = a.raise;
     constexpr int KROW = D * 2 + 16, VROW = D * 2 + 64;
     constexpr int VPR = D / 8, NV = KT * VPR / NT;
     static_assert(NV == 1 || NV == 2, "one or two vectors per thread and tile");
@@ -706,10 +716,17 @@ __global__ __launch_bounds__(512, 1) void paged_attn_prefill_pipe_kernel(PfArgs 
         if (rescale) {
             lrun0 *= alpha;
             lrun1 *= alpha;
+            // (two accumulators per instruction: v_pk_mul_f32)
+            typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+            const f32x2_t a2 = {alpha, alpha};
 #pragma unroll
             for (int db = 0; db < DB; ++db)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2_t o2 = f32x2_t{oacc[db][r], oacc[db][r + 1]} * a2;
+                    oacc[db][r] = o2[0];
+                    oacc[db][r + 1] = o2[1];
+                }
         }
     };
 
@@ -1007,6 +1024,7 @@ int mv_paged_attn_prefill(const void* q, int64_t q_stride, const void* k_cache, 
     a.page_shift = __builtin_ctz((unsigned)page);
     a.num_pages = num_pages;
     a.scale_log2 = scale * 1.4426950408889634f;
+    a.raise = g_pf_raise;
     const int64_t grid = (int64_t)a.nqb * hkv * bs;
     if (grid > 0x7fffffffLL) return MV_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;

@@ -274,7 +274,10 @@ def test_llama3_8b_dimensions_prefill(mv):
         err = (out.float().cpu() - w).abs()
         hin = trace[li].reshape(S, -1).float().abs()
         tol = 1e-3 + 2 ** -7 * w.abs().amax(dim=-1, keepdim=True) + 2 ** -7 * torch.maximum(w.abs(), hin)
-        assert bool((err <= tol).all()), f"prefill layer {li}: max err {err.max().item():.3e}"
+        over = err > tol
+        assert not bool(over.any()), (
+            f"prefill layer {li}: max err {err.max().item():.3e}, {int(over.sum())} of {err.numel()} over the bound, "
+            f"worst ratio {(err / tol).max().item():.2f}")
         # on average: within a small multiple of what the oracle differs from ITSELF on this block
         # when P is kept in fp32 instead of being rounded to bf16 (hidden states of this width are
         # O(1..10), an absolute figure would say nothing)

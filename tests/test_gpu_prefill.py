@@ -104,9 +104,8 @@ def test_prefill_attention_vs_oracle(mv, D, Hq, Hkv, S, starts):
 
 
 def test_prefill_attention_long_chunks_take_256_row_workgroups(mv):
-    """Chunks of 2048 tokens and more whose 256-row workgroups fill the CUs run eight waves per
-    workgroup (one staged K/V tile against 256 stacked query rows); same bounds as above, non-zero
-    starts included."""
+    """Chunks of 512 tokens and more run eight waves per workgroup (one staged K/V tile against 256
+    stacked query rows); same bounds as above, non-zero starts included."""
     from micro_vllm_amd import _native as nv
     from micro_vllm_amd.core.paged_attention import flash_attn_with_kvcache
 
@@ -133,6 +132,8 @@ def test_prefill_attention_long_chunks_take_256_row_workgroups(mv):
     (128, 6, 2, 2048, [3, 0, 129, 64]),                     # three, padded to four in the row stack
     (128, 8, 2, 2100, [0, 1, 63, 64, 65, 200, 256]),        # a last query block that is partly empty
     (64, 4, 2, 2048, [0, 17, 250, 64, 1, 0, 0, 300]),       # heads of 64
+    (128, 8, 2, 600, [0, 100, 257]),                        # mid-size chunks: few workgroups, ragged last tile
+    (64, 4, 4, 513, [5, 0]),
 ])
 def test_prefill_attention_pipelined_form_vs_oracle(mv, D, Hq, Hkv, S, starts):
     """The software-pipelined eight-wave kernel (long chunks) at every stack shape it has: exact
@@ -157,6 +158,48 @@ def test_prefill_attention_pipelined_form_vs_oracle(mv, D, Hq, Hkv, S, starts):
     err = (got.float() - exact.float()).abs()
     tol = 1e-3 + 2 ** -7 * exact.float().abs() + bound
     assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst excess {(err - tol).max().item():.3e}"
+
+
+_LAGGING_MAX_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import micro_vllm_amd
+from test_gpu_prefill import _paged_case
+from oracle.ref_attention import flash_attn_with_kvcache_ref
+from micro_vllm_amd.core.paged_attention import flash_attn_with_kvcache
+D, Hq, Hkv, S, starts = 128, 8, 2, 1100, [0, 200]
+q, k, v, kc, vc, bt, st = _paged_case(2, S, Hq, Hkv, D, starts, seed=5, n_pages=12, max_blocks=6)
+# scores that keep growing along the keys: every block raises the maximum a little
+ramp = torch.linspace(0.5, 3.0, S).reshape(1, S, 1, 1)
+k = (k.float() * ramp).to(torch.bfloat16)
+kc1, vc1 = kc.clone(), vc.clone()
+exact, bound = flash_attn_with_kvcache_ref(q, kc1, vc1, k, v, None, None, st, bt, causal=True, p_bf16=False,
+                                           return_p_bound=True)
+got = flash_attn_with_kvcache(q.cuda(), kc.cuda(), vc.cuda(), k=k.cuda(), v=v.cuda(), cache_seqlens=st.cuda(),
+                              block_table=bt.cuda(), causal=True).cpu()
+err = (got.float() - exact.float()).abs()
+# a weight may now be as large as 2^8 when it is rounded: the rounding bound grows with it, by no
+# more than the factor by which the largest weight may exceed 1 in the normalised sum (it does not:
+# numerator and normaliser carry the same scale) - the same bound is asked for
+tol = 1e-3 + 2 ** -7 * exact.float().abs() + bound
+print("MAXERR", float(err.max()), "EXCESS", float((err - tol).max()))
+assert bool((err <= tol).all())
+"""
+
+
+def test_prefill_attention_with_a_lagging_maximum_stays_within_the_same_bounds(mv):
+    """MVLLM_PREFILL_ATTN_RAISE=8 (read once per process: a child process) - the running maximum
+    follows only jumps of more than 2^8 - on keys whose scores keep growing along the sequence:
+    same bound against the exact softmax as the default."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _LAGGING_MAX_CHILD, root], capture_output=True, text=True, timeout=280,
+                       env=dict(os.environ, MVLLM_PREFILL_ATTN_RAISE="8"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    assert "MAXERR" in r.stdout
 
 
 def _build(mv, shape, qkv_bias=False, n_blocks=24, max_bs=4, p_bf16=False):

@@ -61,8 +61,9 @@ def test_prefill_forms(mv):
     assert L.mv_gemm_prefill_form(4096, 4100, 4096) == 0       # not a shape the kernels take at all
     # attention: 256-row workgroups for long chunks that fill their rounds
     assert L.mv_paged_attn_prefill_form(1, 4096, 32, 8) == 8
-    assert L.mv_paged_attn_prefill_form(1, 3072, 32, 8) == 4   # 384 workgroups on 256 CUs
-    assert L.mv_paged_attn_prefill_form(8, 1024, 32, 8) == 4   # short chunks
+    assert L.mv_paged_attn_prefill_form(1, 3072, 32, 8) == 8
+    assert L.mv_paged_attn_prefill_form(8, 1024, 32, 8) == 8
+    assert L.mv_paged_attn_prefill_form(8, 511, 32, 8) == 4    # short chunks
     assert L.mv_paged_attn_prefill_form(1, 0, 32, 8) == 0
 
 
