@@ -134,6 +134,7 @@ def test_prefill_attention_long_chunks_take_256_row_workgroups(mv):
     (64, 4, 2, 2048, [0, 17, 250, 64, 1, 0, 0, 300]),       # heads of 64
     (128, 8, 2, 600, [0, 100, 257]),                        # mid-size chunks: few workgroups, ragged last tile
     (64, 4, 4, 513, [5, 0]),
+    (128, 8, 2, 600, [1500, 0, 700]),                       # chunks late in a sequence: long runs of unmasked tiles
 ])
 def test_prefill_attention_pipelined_form_vs_oracle(mv, D, Hq, Hkv, S, starts):
     """The software-pipelined eight-wave kernel (long chunks) at every stack shape it has: exact
