@@ -125,18 +125,20 @@ def test_prefill_attention_long_chunks_take_256_row_workgroups(mv):
     assert bool((err <= tol).all()), f"max err {err.max().item():.3e}, worst excess {(err - tol).max().item():.3e}"
 
 
-@pytest.mark.parametrize("D,Hq,Hkv,S,starts", [
-    (128, 8, 2, 2048, [0, 256, 5, 300]),                    # four query heads per kv head (the 8B ratio)
-    (128, 4, 4, 2048, [0, 7, 64, 100, 300, 1, 31, 255]),    # one: 256 positions per workgroup
-    (128, 16, 2, 2048, [0, 33]),                            # eight: 32 positions per workgroup
-    (128, 6, 2, 2048, [3, 0, 129, 64]),                     # three, padded to four in the row stack
-    (128, 8, 2, 2100, [0, 1, 63, 64, 65, 200, 256]),        # a last query block that is partly empty
-    (64, 4, 2, 2048, [0, 17, 250, 64, 1, 0, 0, 300]),       # heads of 64
-    (128, 8, 2, 600, [0, 100, 257]),                        # mid-size chunks: few workgroups, ragged last tile
-    (64, 4, 4, 513, [5, 0]),
-    (128, 8, 2, 600, [1500, 0, 700]),                       # chunks late in a sequence: long runs of unmasked tiles
+@pytest.mark.parametrize("D,Hq,Hkv,S,starts,page", [
+    (128, 8, 2, 2048, [0, 256, 5, 300], 256),                    # four query heads per kv head (the 8B ratio)
+    (128, 4, 4, 2048, [0, 7, 64, 100, 300, 1, 31, 255], 256),    # one: 256 positions per workgroup
+    (128, 16, 2, 2048, [0, 33], 256),                            # eight: 32 positions per workgroup
+    (128, 6, 2, 2048, [3, 0, 129, 64], 256),                     # three, padded to four in the row stack
+    (128, 8, 2, 2100, [0, 1, 63, 64, 65, 200, 256], 256),        # a last query block that is partly empty
+    (64, 4, 2, 2048, [0, 17, 250, 64, 1, 0, 0, 300], 256),       # heads of 64
+    (128, 8, 2, 600, [0, 100, 257], 256),                        # mid-size chunks: few workgroups, ragged last tile
+    (64, 4, 4, 513, [5, 0], 256),
+    (128, 8, 2, 600, [1500, 0, 700], 256),                       # chunks late in a sequence: long runs of unmasked tiles
+    (128, 8, 2, 600, [70, 0], 64),                          # a page per key tile: every tile looks its page up
+    (64, 4, 2, 520, [0, 33], 128),
 ])
-def test_prefill_attention_pipelined_form_vs_oracle(mv, D, Hq, Hkv, S, starts):
+def test_prefill_attention_pipelined_form_vs_oracle(mv, D, Hq, Hkv, S, starts, page):
     """The software-pipelined eight-wave kernel (long chunks) at every stack shape it has: exact
     append, output within the same bounds as the plain kernel above.  The first tiles of a sequence
     that starts at 0, the masked tiles on the diagonal (starts that are not multiples of 32 or 64
@@ -146,9 +148,9 @@ def test_prefill_attention_pipelined_form_vs_oracle(mv, D, Hq, Hkv, S, starts):
 
     B = len(starts)
     assert nv.lib().mv_paged_attn_prefill_form(B, S, Hq, Hkv) == 8, "meant to take the 8-wave form"
-    need = sum((st + S + 255) // 256 for st in starts)
-    q, k, v, kc, vc, bt, st = _paged_case(B, S, Hq, Hkv, D, starts, seed=S + D + Hq, n_pages=need + 3,
-                                          max_blocks=(max(starts) + S + 255) // 256 + 1)
+    need = sum((st + S + page - 1) // page for st in starts)
+    q, k, v, kc, vc, bt, st = _paged_case(B, S, Hq, Hkv, D, starts, page=page, seed=S + D + Hq, n_pages=need + 3,
+                                          max_blocks=(max(starts) + S + page - 1) // page + 1)
     kc1, vc1 = kc.clone(), vc.clone()
     exact, bound = flash_attn_with_kvcache_ref(q, kc1, vc1, k, v, None, None, st, bt, causal=True,
                                                p_bf16=False, return_p_bound=True)
