@@ -117,6 +117,7 @@ def prefill_leg(args, cfg, layers, runner, dev, reps=3):
     """Second half of the metric: one fixed-length prefill of `ctx` tokens (bs 1) through
     ModelPrefillRunner on the same weight image, KV pages written, last-token logits.  Timed with
     HIP events on the current stream; flops = 2 * params * tokens + causal attention."""
+    from micro_vllm_amd import _native as nv
     from micro_vllm_amd.core.cache_manager import KVCacheManager
     from micro_vllm_amd.core.layer.model_prefill import ModelPrefillRunner
 
@@ -153,6 +154,9 @@ def prefill_leg(args, cfg, layers, runner, dev, reps=3):
             "ms": round(t * 1e3, 3), "seq_len": S, "batch": 1, "bound": "mfma",
             "achieved_TFLOPs": round(flops / t / 1e12, 1), "peak_TFLOPs": MFMA_PEAK_TFLOPS,
             "frac": round(flops / t / 1e12 / MFMA_PEAK_TFLOPS, 4),
+            "attention": {"waves_per_workgroup": int(nv.lib().mv_paged_attn_prefill_form(
+                              1, S, cfg.num_attention_heads, cfg.num_key_value_heads)),
+                          "running_maximum_may_lag_by_pow2": float(os.environ.get("MVLLM_PREFILL_ATTN_RAISE") or 0)},
             "logits": "last position only (what the engine samples from)"}
 
 
