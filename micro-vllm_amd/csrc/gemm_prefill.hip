@@ -77,6 +77,22 @@ static __device__ unsigned long long g_stamp[4 * 512];
 #else
 #define MV_STAMP(slot) do {} while (0)
 #endif
+#ifdef MV_GEMM_WSTAMP
+// Wide form, tools/stamp_gemm_wide.py: wall-clock ticks (100 MHz) of wave 0 of workgroup kWStampBlock at
+// the top of every second k-tile and on either side of a tile's output stores; slot = tile-local
+// index + (nkt + 2) * tile.
+constexpr int kWStampBlock = 77;
+static __device__ unsigned long long g_wstamp[4096];
+#define MV_WSTAMP(i)                                                                         \
+    do {                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        const int si_ = (i) - g0 + tile_no * (nkt + 2);                                      \
+        if (blockIdx.x == kWStampBlock && threadIdx.x == 0 && si_ < 4096) g_wstamp[si_] = wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+    } while (0)
+#else
+#define MV_WSTAMP(i) do {} while (0)
+#endif
 // MV_EXP_NO_MFMA (timing experiment, wrong results): operands are delivered and consumed by an empty
 // asm statement instead of the matrix instruction; MV_EXP_NO_BARRIER drops the per-stage barrier.
 #ifdef MV_EXP_NO_MFMA
@@ -87,52 +103,143 @@ static __device__ unsigned long long g_stamp[4 * 512];
 
 // One wave's 64 (n) x 128 (m) block of accumulators to memory, with the projection epilogue:
 // acc[i][t][j] = C[n = 16 (nt0+i) + 4q + j][m = m0 + 16 t + r]
+// The epilogue loops below are fully unrolled and go row by row (t outside, the tiles of the row
+// inside), with a scheduling fence per row: the row's addresses are then formed once, used and dropped;
+// run side by side, the rows' temporaries do not fit beside 128 accumulators and the operand
+// fragments already fetched for the next tile.
+#define MV_EPI_FENCE __builtin_amdgcn_sched_barrier(0)
+
+// silu(gate) * up on two accumulators rounded to bf16, as silu_mul_rounded, with the hardware's
+// exp2 and reciprocal (1 ulp each) in place of the library exp and the IEEE division: 10 vector
+// instructions instead of 33.  A tile's epilogue forms 64 of these per lane while the matrix pipe
+// waits.  Against the same product formed in fp64 from the same rounded accumulators (29 M outputs
+// of the 8B gate/up shape, tools/check_quick_silu.py): 16 outputs in 10^6 differ, by one bf16 ulp;
+// with the library exp and the IEEE division 7 in 10^6 do.
+__device__ __forceinline__ float silu_mul_rounded_quick(float gate_acc, float up_acc) {
+    const float g = round_bf16(gate_acc), u = round_bf16(up_acc);
+    const float e = __builtin_amdgcn_exp2f(g * -1.44269504088896341f);
+    const float sig = __builtin_amdgcn_rcpf(1.0f + e);
+    return (g * sig) * u;
+}
 template <int NT>
 __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_t (&acc)[NT][kPMT], int nt0,
                                                 int m0, int ks, int r, int q) {
     const bool sw = (a.flags & MV_GEMM_SWIGLU) != 0, of32 = (a.flags & MV_GEMM_OUT_F32) != 0;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) {
-        const int nt = nt0 + i;
-        if (nt >= a.nt) continue;  // uniform
-        const int n0 = nt * 16 + q * 4;
+    if (a.partial) {
 #pragma unroll
         for (int t = 0; t < kPMT; ++t) {
+            MV_EPI_FENCE;
             const int m = m0 + t * 16 + r;
-            const f32x4_t c = acc[i][t];
-            if (a.partial) {
+            float* const row = a.partial + ((int64_t)ks * a.m + min(m, a.m - 1)) * a.n + nt0 * 16 + q * 4;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                if (nt0 + i < a.nt && m < a.m) *reinterpret_cast<f32x4_t*>(row + i * 16) = acc[i][t];
+        }
+        return;
+    }
+    if (sw) {
+        // Rows 0..7 of a tile are up, 8..15 the matching gates: lane l < 32 holds four up values and
+        // lane l + 32 their gates.  Two v_permlane32_swap leave the lower lane (up, gate) of columns
+        // 0, 1 of its four and the upper lane those of columns 2, 3, so that every lane forms two of
+        // the products instead of half the lanes forming four.  A lane then holds one dword (two
+        // outputs) of each of the wave's tiles, and the four lanes of a row hold the 16 bytes of a
+        // tile between them: a 4 x 4 transposition across those lanes (tiles 0 <-> 2, 1 <-> 3 by
+        // v_permlane32_swap, then 0 <-> 1, 2 <-> 3 by v_permlane16_swap) gives lane (r, q) all of tile
+        // q - one 16-byte store per row and lane, 64 contiguous bytes per row and instruction, where
+        // dword stores covered 16.
+        const bool whole = (a.ldy % 8) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+#pragma unroll
+        for (int t = 0; t < kPMT; ++t) {
+            MV_EPI_FENCE;
+            const int m = m0 + t * 16 + r;
+            uint16_t* const row = reinterpret_cast<uint16_t*>(a.y) + (int64_t)min(m, a.m - 1) * a.ldy + nt0 * 8;
+            uint32_t o[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const f32x4_t c = acc[i][t];
+                const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(c[2]), false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[1]), __float_as_uint(c[3]), false, false);
+                o[i] = pack_bf16x2(silu_mul_rounded_quick(__uint_as_float(s0[1]), __uint_as_float(s0[0])),
+                                   silu_mul_rounded_quick(__uint_as_float(s1[1]), __uint_as_float(s1[0])));
+            }
+#ifdef MV_EXP_EPI_NO_WRITE
+            asm volatile("" : : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));   // timing experiment only
+#else
+            if (whole) {
+                const auto a02 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
+                const auto a13 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
+                const auto lo = __builtin_amdgcn_permlane16_swap(a02[0], a13[0], false, false);   // columns 0,1 | 4,5
+                const auto hi = __builtin_amdgcn_permlane16_swap(a02[1], a13[1], false, false);   // columns 2,3 | 6,7
+                if (m < a.m && q < NT && nt0 + q < a.nt)
+                    *reinterpret_cast<uint4*>(row + q * 8) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    if (m < a.m && nt0 + i < a.nt)
+                        *reinterpret_cast<uint32_t*>(row + i * 8 + (q & 1) * 4 + (q >> 1) * 2) = o[i];
+            }
+#endif
+        }
+        return;
+    }
+    if (of32) {
+#pragma unroll
+        for (int t = 0; t < kPMT; ++t) {
+            MV_EPI_FENCE;
+            const int m = m0 + t * 16 + r;
+            float* const row = reinterpret_cast<float*>(a.y) + (int64_t)min(m, a.m - 1) * a.ldy + nt0 * 16 + q * 4;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                if (nt0 + i < a.nt && m < a.m) *reinterpret_cast<f32x4_t*>(row + i * 16) = acc[i][t];
+        }
+        return;
+    }
+    // bf16 output: four columns (8 bytes) of one row per lane and tile; t = bf16(acc), + bias, + residual
+    // with a rounding after each
+    auto rounded = [&](const f32x4_t& c, const uint16_t* bias, const uint16_t* res) __attribute__((always_inline)) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float tv = round_bf16(c[j]);
+            if (a.bias) tv = round_bf16(tv + bf16_bits_to_f32(bias[j]));
+            if (a.residual) tv = round_bf16(tv + bf16_bits_to_f32(res[j]));
+            v[j] = tv;
+        }
+        uint2 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], v[3]);
+        return o;
+    };
+    // Two neighbouring tiles at a time where the rows allow 16-byte stores: v_permlane16_swap
+    // exchanges the odd 16-lane rows (q = 1, 3) of the first tile's registers with the even rows of
+    // the second's, after which lane (r, q) holds columns 8 (q >> 1) .. + 7 of tile i + (q & 1) - a
+    // store instruction then covers 64 contiguous bytes of each of its 16 rows instead of 32.
+    const bool pairs = (a.ldy % 8) == 0 && (reinterpret_cast<uintptr_t>(a.y) & 15) == 0;
+#pragma unroll
+    for (int t = 0; t < kPMT; ++t) {
+        MV_EPI_FENCE;
+        const int m = m0 + t * 16 + r, mc = min(m, a.m - 1);
+        uint16_t* const row = reinterpret_cast<uint16_t*>(a.y) + (int64_t)mc * a.ldy + nt0 * 16;
+        const uint16_t* const res = a.residual ? a.residual + (int64_t)mc * a.ld_res + nt0 * 16 + q * 4 : nullptr;
+        const uint16_t* const bias = a.bias ? a.bias + nt0 * 16 + q * 4 : nullptr;
+#pragma unroll
+        for (int i = 0; i < NT; i += 2) {
+            if (nt0 + i >= a.nt) continue;  // uniform
+            if (i + 1 < NT && pairs && nt0 + i + 1 < a.nt) {
+                constexpr int kLast = NT - 1;
+                const uint2 p0 = rounded(acc[i][t], bias + i * 16, res + i * 16);
+                const uint2 p1 = rounded(acc[i + 1 < NT ? i + 1 : kLast][t], bias + (i + 1) * 16, res + (i + 1) * 16);
+                const auto rx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
+                const auto ry = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
                 if (m < a.m)
-                    *reinterpret_cast<f32x4_t*>(&a.partial[((int64_t)ks * a.m + m) * a.n + n0]) = c;
-            } else if (sw) {
-                // rows 0..7 of the tile are up, 8..15 the matching gates: 32 lanes further
-                f32x4_t g;
+                    *reinterpret_cast<uint4*>(row + (i + (q & 1)) * 16 + (q >> 1) * 8) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            } else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) g[j] = __shfl_xor(c[j], 32, 64);
-                if (q < 2 && m < a.m) {
-                    uint2 o;
-                    o.x = pack_bf16x2(silu_mul_rounded(g[0], c[0]), silu_mul_rounded(g[1], c[1]));
-                    o.y = pack_bf16x2(silu_mul_rounded(g[2], c[2]), silu_mul_rounded(g[3], c[3]));
-                    *reinterpret_cast<uint2*>(
-                        &reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + nt * 8 + q * 4]) = o;
-                }
-            } else if (m < a.m) {
-                if (of32) {
-                    *reinterpret_cast<f32x4_t*>(&reinterpret_cast<float*>(a.y)[(int64_t)m * a.ldy + n0]) = c;
-                } else {
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float tv = round_bf16(c[j]);
-                        if (a.bias) tv = round_bf16(tv + bf16_bits_to_f32(a.bias[n0 + j]));
-                        if (a.residual)
-                            tv = round_bf16(tv + bf16_bits_to_f32(a.residual[(int64_t)m * a.ld_res + n0 + j]));
-                        v[j] = tv;
+                for (int ii = i; ii < i + 2 && ii < NT; ++ii)
+                    if (nt0 + ii < a.nt) {  // uniform
+                        const uint2 o = rounded(acc[ii][t], bias + ii * 16, res + ii * 16);
+                        if (m < a.m) *reinterpret_cast<uint2*>(row + ii * 16 + q * 4) = o;
                     }
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(&reinterpret_cast<uint16_t*>(a.y)[(int64_t)m * a.ldy + n0]) = o;
-                }
             }
         }
     }
@@ -339,64 +446,93 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
 
-    // blockIdx -> tile.  An XCD (blockIdx mod 8) owns a contiguous range of n-blocks and walks it in
-    // bands of `mband` m-blocks: m fastest inside the band, then n, then the next band - so the 32
-    // workgroups resident on the XCD at one time are mband x 32/mband tiles (8 x 4 at 2048 tokens and
-    // more) rather than one long column, and the operand rows they pull through that XCD's L2
-    // together are as few as 32 tiles allow.
+    // Tile ids of this workgroup: blockIdx.x, + gridDim.x, ... (the grid is one workgroup per CU, or
+    // one per tile id).  A workgroup that has a further tile never drains its pipeline between the
+    // two: the copies issued during the last four k-tiles of a tile already bring the first weight
+    // tiles and x stages of the next one into the ring slots that fall free, the output stores of the
+    // finished tile are left in flight, and the accumulators start again from zero.  A round of tiles
+    // otherwise costs about 20 us that no MFMA covers (every CU of the chip filling its rings from
+    // cold at the same moment, and every CU waiting for its output stores before the next workgroup
+    // may start): measured on one round, 0.745 us per k-tile + 22.8 us.
+    //
+    // id -> tile.  An XCD (id mod 8; the stride is a multiple of 8) owns a contiguous range of
+    // n-blocks and walks it in bands of `mband` m-blocks: m fastest inside the band, then n, then the
+    // next band - so the 32 workgroups resident on the XCD at one time are mband x 32/mband tiles
+    // (8 x 4 at 2048 tokens and more) rather than one long column, and the operand rows they pull
+    // through that XCD's L2 together are as few as 32 tiles allow.
+    //
+    // Copy sources of this wave in a tile: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles
+    // likewise.  Every copy is addressed as a wave-uniform 64-bit base (scalar registers) plus a
+    // 32-bit per-lane offset that changes only with the tile: no vector arithmetic and half the
+    // address registers per copy instruction.
+    struct Tile {
+        const unsigned char* wbase[2];
+        const unsigned char* xbase[2];
+        unsigned xlane[4];
+        int ks, m0, ntb;
+    };
     const int tiles = 8 * a.nb_per_xcd * a.mblocks;
-    const int ks = blockIdx.x / tiles, bid = blockIdx.x - ks * tiles;   // k-slice (see the host side), tile
-    const int kt0 = ks * a.ktps, nkt = a.ktps;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int per_band = a.mband * a.nb_per_xcd;
-    const int band = min(idx / per_band, (a.mblocks - 1) / a.mband);
-    const int rows = min(a.mband, a.mblocks - band * a.mband);
-    const int j = idx - band * per_band;
-    const int nbl = j / rows;
-    const int nb = xcd * a.nb_per_xcd + nbl;
-    const int mb = band * a.mband + j % rows;
-    if (nb >= a.nblocks || nbl >= a.nb_per_xcd) return;
-    const int m0 = mb * kWM;
-    const int ntb = nb * width;
-    const int nstage = nkt >> 1;
-
-    // ---- copy sources of this wave: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles likewise.
-    // Every copy is addressed as a wave-uniform 64-bit base (scalar registers, advanced by scalar
-    // adds per k-tile) plus a 32-bit per-lane offset that never changes: no vector arithmetic and
-    // half the address registers per copy instruction.
-    const unsigned char* wbase[2];
+    const int total = tiles * a.ksplit, stride = gridDim.x;
+    const int nkt = a.ktps, nstage = nkt >> 1;
+    auto decode = [&](int id, Tile& tl) __attribute__((always_inline)) -> bool {
+        const int ks = id / tiles, bid = id - ks * tiles;   // k-slice (see the host side), tile
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int per_band = a.mband * a.nb_per_xcd;
+        const int band = min(idx / per_band, (a.mblocks - 1) / a.mband);
+        const int rows = min(a.mband, a.mblocks - band * a.mband);
+        const int j = idx - band * per_band;
+        const int nbl = j / rows;
+        const int nb = xcd * a.nb_per_xcd + nbl;
+        const int mb = band * a.mband + j % rows;
+        if (nb >= a.nblocks || nbl >= a.nb_per_xcd) return false;
+        const int kt0 = ks * a.ktps;
+        tl.ks = ks;
+        tl.m0 = mb * kWM;
+        tl.ntb = nb * width;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-        wbase[j] = reinterpret_cast<const unsigned char*>(a.w + ((int64_t)min(ntb + 2 * wid + j, a.nt - 1) * a.kt + kt0) * 64);
+        for (int j = 0; j < 2; ++j)
+            tl.wbase[j] = reinterpret_cast<const unsigned char*>(a.w + ((int64_t)min(tl.ntb + 2 * wid + j, a.nt - 1) * a.kt + kt0) * 64);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int first = min(tl.m0 + (2 * wid + (j >> 1)) * 16, a.m - 1);   // first row of the m-tile (clamped)
+            const int row = (j & 1) * 8 + (lane >> 3);                             // row of the m-tile
+            const int c = (lane & 7) ^ ((row >> 1) & 7);                           // the chunk that lives at position lane & 7
+            const int grow = min(tl.m0 + (2 * wid + (j >> 1)) * 16 + row, a.m - 1);
+            if ((j & 1) == 0) tl.xbase[j >> 1] = reinterpret_cast<const unsigned char*>(a.x + (int64_t)first * a.ldx + kt0 * 32);
+            tl.xlane[j] = (unsigned)(((int64_t)(grow - first) * a.ldx + c * 8) * 2);
+        }
+        return true;
+    };
+    Tile cur, nxt;
+    int id = blockIdx.x;
+    while (id < total && !decode(id, cur)) id += stride;
+    if (id >= total) return;
+    // the tile after `from`; with none left `nxt` repeats `cur`, whose first k-tiles are then fetched
+    // once more into slots nobody reads (the copy counts per k-tile stay fixed)
+    auto following = [&](int from) __attribute__((always_inline)) {
+        int n = from + stride;
+        while (n < total && !decode(n, nxt)) n += stride;
+        if (n >= total) nxt = cur;
+        return n;
+    };
+    int nid = following(id);
     const unsigned wlane = lane * 16;
-    const unsigned char* xbase[2];
-    unsigned xlane[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int first = min(m0 + (2 * wid + (j >> 1)) * 16, a.m - 1);   // first row of the m-tile (clamped)
-        const int row = (j & 1) * 8 + (lane >> 3);                          // row of the m-tile
-        const int c = (lane & 7) ^ ((row >> 1) & 7);                        // the chunk that lives at position lane & 7
-        const int grow = min(m0 + (2 * wid + (j >> 1)) * 16 + row, a.m - 1);
-        if ((j & 1) == 0) xbase[j >> 1] = reinterpret_cast<const unsigned char*>(a.x + (int64_t)first * a.ldx + kt0 * 32);
-        xlane[j] = (unsigned)(((int64_t)(grow - first) * a.ldx + c * 8) * 2);
-    }
     const unsigned x_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xring;
     const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wring;
     auto copy = [&](const unsigned char* base, unsigned lane_off, unsigned dst) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      : : "v"(lane_off), "s"(base), "s"(dst) : "memory");
     };
+    // the ring fill in front of a workgroup's first tile (a slice has at least 8 k-tiles)
     auto copy_w = [&](int kt, int slot) {
-        const int ktc = min(kt, nkt - 1);   // past the end: a harmless re-fetch keeps the counts fixed
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            copy(wbase[j] + (int64_t)ktc * 1024, wlane, w_lds + slot * kWWSlot + (2 * wid + j) * 1024);
+            copy(cur.wbase[j] + (int64_t)kt * 1024, wlane, w_lds + slot * kWWSlot + (2 * wid + j) * 1024);
     };
     auto copy_x = [&](int st, int slot) {
-        const int sc = min(st, nstage - 1);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            copy(xbase[j >> 1] + sc * 128, xlane[j], x_lds + slot * kWXSlot + (2 * wid + (j >> 1)) * 2048 + (j & 1) * 1024);
+            copy(cur.xbase[j >> 1] + st * 128, cur.xlane[j], x_lds + slot * kWXSlot + (2 * wid + (j >> 1)) * 2048 + (j & 1) * 1024);
     };
     // fragment reads: per-lane byte offsets inside a slot
     const int xoff0 = (wm * 8) * 2048 + r * 128 + (((0 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 0
@@ -445,27 +581,36 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
     // fragment reads for about as long, and with both waves of a SIMD in step (the barrier keeps
     // them so) the matrix pipe idles through every such block; between short MFMA groups the
     // partner's MFMAs fill it.
-    auto copy_piece = [&](int kt, bool odd, int p) {
+    // `kt` counts inside the tile, `g` over all k-tiles of this workgroup (the ring slots go by g);
+    // what lies past the end of the tile is taken from the start of the next one
+    auto copy_piece = [&](int g, int kt, bool odd, int p) {
         // pieces of this k-tile in issue order: on odd k-tiles the four x pieces first
         const int nx = odd ? 4 : 0;
         if (p < nx) {
-            const int st = min((kt >> 1) + 3, nstage - 1), slot = (kt >> 1) % 3;
-            copy(xbase[p >> 1] + st * 128, xlane[p], x_lds + slot * kWXSlot + (2 * wid + (p >> 1)) * 2048 + (p & 1) * 1024);
+            const int s3 = (kt >> 1) + 3, slot = (g >> 1) % 3;
+            const bool over = s3 >= nstage;
+            const unsigned char* base = over ? nxt.xbase[p >> 1] : cur.xbase[p >> 1];
+            const int st = over ? s3 - nstage : s3;
+            copy(base + st * 128, over ? nxt.xlane[p] : cur.xlane[p],
+                 x_lds + slot * kWXSlot + (2 * wid + (p >> 1)) * 2048 + (p & 1) * 1024);
         } else if (p < nx + 2) {
-            const int j = p - nx, ktc = min(kt + 4, nkt - 1);
-            copy(wbase[j] + (int64_t)ktc * 1024, wlane, w_lds + (kt & 3) * kWWSlot + (2 * wid + j) * 1024);
+            const int j = p - nx, k4 = kt + 4;
+            const bool over = k4 >= nkt;
+            const unsigned char* base = over ? nxt.wbase[j] : cur.wbase[j];
+            const int ktc = over ? k4 - nkt : k4;
+            copy(base + (int64_t)ktc * 1024, wlane, w_lds + (g & 3) * kWWSlot + (2 * wid + j) * 1024);
         }
     };
-    auto ktile = [&](bf16x8_t(&wc)[NT], bf16x8_t(&xc)[kPMT], bf16x8_t(&wnx)[NT], bf16x8_t(&xnx)[kPMT], int kt,
-                     bool odd) {
-        const int ktn = min(kt + 1, nkt - 1);
-        const unsigned char* wp = wring + (ktn & 3) * kWWSlot + woff;
-        const unsigned char* xp = xring + ((ktn >> 1) % 3) * kWXSlot + ((ktn & 1) ? xoff1 : xoff0);
+    auto ktile = [&](bf16x8_t(&wc)[NT], bf16x8_t(&xc)[kPMT], bf16x8_t(&wnx)[NT], bf16x8_t(&xnx)[kPMT], int g,
+                     int kt, bool odd) {
+        const int gn = g + 1;
+        const unsigned char* wp = wring + (gn & 3) * kWWSlot + woff;
+        const unsigned char* xp = xring + ((gn >> 1) % 3) * kWXSlot + ((gn & 1) ? xoff1 : xoff0);
 #pragma unroll
         for (int t = 0; t < kPMT; ++t) {
             __builtin_amdgcn_sched_barrier(0);
 #ifndef MV_EXP_NO_COPY
-            if (t < 6) copy_piece(kt, odd, t);
+            if (t < 6) copy_piece(g, kt, odd, t);
 #endif
             __builtin_amdgcn_sched_barrier(0);
 #ifndef MV_EXP_NO_FRAG_READ
@@ -491,14 +636,34 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
         __syncthreads();
 #endif
     };
-    for (int kt = 0; kt < nkt; kt += 2) {   // a slice is a multiple of 64 k (checked on the host)
-        ktile(wA, xA, wB, xB, kt, false);
-        ktile(wB, xB, wA, xA, kt + 1, true);
+    [[maybe_unused]] int tile_no = 0;
+    for (int g0 = 0;; g0 += nkt) {
+        for (int kt = 0; kt < nkt; kt += 2) {   // a slice is a multiple of 64 k (checked on the host)
+            MV_WSTAMP(g0 + kt);
+            ktile(wA, xA, wB, xB, g0 + kt, kt, false);
+            ktile(wB, xB, wA, xA, g0 + kt + 1, kt + 1, true);
+        }
+        MV_WSTAMP(g0 + nkt);
+#ifdef MV_EXP_NO_STORE
+        // timing experiment only: the accumulators are consumed, nothing is written
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int t = 0; t < kPMT; ++t) asm volatile("" : : "v"(acc[i][t]));
+#else
+        if (cur.ntb + wcol < a.nt) store_wave_tile<NT>(a, acc, cur.ntb + wcol, cur.m0 + wm * 128, cur.ks, r, q);
+#endif
+        MV_WSTAMP(g0 + nkt + 1);
+        if (nid >= total) break;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int t = 0; t < kPMT; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        cur = nxt;
+        nid = following(nid);
+        ++tile_no;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after this workgroup is gone
-
-    if (ntb + wcol >= a.nt) return;
-    store_wave_tile<NT>(a, acc, ntb + wcol, m0 + wm * 128, ks, r, q);
 }
 
 // Tile width: wave column c of wave row wm takes NTA n-tiles when c + wm is even and NTB otherwise, so
@@ -527,6 +692,11 @@ __global__ __launch_bounds__(512, 1) void gemm_prefill_wide_kernel(PGemmArgs a) 
 
 }  // namespace mv
 
+#ifdef MV_GEMM_WSTAMP
+extern "C" int mv_debug_read_wide_stamps(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_wstamp), bytes) == hipSuccess ? 0 : -3;
+}
+#endif
 #ifdef MV_GEMM_STAMP
 extern "C" int mv_debug_read_stamps(void* dst, size_t bytes) {
     return hipMemcpyFromSymbol(dst, HIP_SYMBOL(mv::g_stamp), bytes) == hipSuccess ? 0 : -3;
@@ -712,8 +882,16 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
             const int v = atoi(e);
             a.mband = v <= 0 || v > a.mblocks ? a.mblocks : v;
         }
-        const long wgrid = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
-        if (wgrid > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
+        const long ids = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
+        if (ids > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
+        // one workgroup per CU walks the tile ids with that stride (a multiple of 8: an id keeps its
+        // XCD); MVLLM_PREFILL_PERSIST = 0 launches one workgroup per id instead (read once)
+        static const bool persist = [] {
+            const char* e = getenv("MVLLM_PREFILL_PERSIST");
+            return !(e && *e) || atoi(e) != 0;
+        }();
+        const long resident = std::max(8, num_cus() / 8 * 8);
+        const long wgrid = persist ? std::min(ids, resident) : ids;
         if (strips == 12)
             hipLaunchKernelGGL((gemm_prefill_wide_kernel<3, 3>), dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
         else if (strips == 14)

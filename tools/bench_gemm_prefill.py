@@ -15,7 +15,9 @@ for m in ms:
               for _ in range(copies)]
         pad = int(os.environ.get("XPAD", "0"))     # extra elements per row of x (row stride k + pad)
         x = torch.randn(m, k + pad, device=dev).to(torch.bfloat16)[:, :k]
-        y = torch.empty(m, n // 2 if sw else n, dtype=torch.bfloat16, device=dev)
+        ypad = int(os.environ.get("YPAD", "0"))    # extra elements per row of y
+        nc = n // 2 if sw else n
+        y = torch.empty(m, nc + ypad, dtype=torch.bfloat16, device=dev)[:, :nc]
         for w in ws:
             gemm_prefill(x, w, y, swiglu=sw)
         torch.cuda.synchronize()
