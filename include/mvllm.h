@@ -197,10 +197,15 @@ int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void*
                     const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,
                     int k, int flags, mv_stream_t stream);
 
-/* The same with a workspace for k-slices: when M x N alone gives fewer output tiles than the chip
- * has CUs (prompts of up to a few hundred tokens), k is cut into slices that run side by side and
- * a second launch adds them (fp32, in order) and applies the epilogue.  Without the workspace
- * (or with too small a one) the call behaves like mv_gemm_prefill. */
+/* The same with a workspace for sums over parts of k.  When M x N alone gives fewer output tiles
+ * than the chip has CUs (prompts of up to a few hundred tokens), k is cut into slices that run side
+ * by side and a second launch adds them (fp32, in order) and applies the epilogue.  When there are
+ * more 256-wide tiles than CUs and the last round of tiles would leave half the CUs or more idle,
+ * the tiles of that round are cut along k between the workgroups of the one launch: the lower parts
+ * leave their accumulators in the workspace (256 KiB per workgroup) and the workgroup with the last
+ * part adds them, in part order, as it applies the epilogue.  That path keeps per-device counters
+ * inside the library, so two launches that take it must not overlap on one GPU.  Without the
+ * workspace (or with too small a one) the call behaves like mv_gemm_prefill. */
 size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k);
 int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
                        const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,
@@ -212,6 +217,11 @@ int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const vo
  * with tiles of 192 and of 224 columns, where those fill the CUs in fewer or fuller rounds
  * (MVLLM_PREFILL_WIDE_STRIPS=12/14/16 forces the width, in 16-column strips). */
 int mv_gemm_prefill_form(int m, int n, int k);
+/* Overrides for tests and A/B runs inside one process (no counterpart in the reference): cut = 0 / 1
+ * switches the cutting of left-over tiles off / on, strips = 12 / 14 / 16 forces the tile width, for
+ * every call that follows; -1 returns a choice to the environment (MVLLM_PREFILL_CUT,
+ * MVLLM_PREFILL_WIDE_STRIPS) and the planner.  Process-wide; not for use beside running calls. */
+void mv_debug_prefill_options(int cut, int strips);
 
 /* ---------------------------------------------------- paged attention */
 

@@ -69,6 +69,7 @@ PROTOTYPES = {
     "mv_gemm_prefill": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P]),
     "mv_gemm_prefill_workspace_bytes": (_Z, [_I, _I, _I]),
     "mv_gemm_prefill_form": (_I, [_I, _I, _I]),
+    "mv_debug_prefill_options": (None, [_I, _I]),
     "mv_paged_attn_prefill_form": (_I, [_I, _I, _I, _I]),
     "mv_gemm_prefill_ws": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _I, _I, _I, _I, _P, _Z, _P]),
     "mv_rope_prefill": (_I, [_P, _L, _P, _L, _P, _P, _I, _L, _I, _I, _I, _P]),

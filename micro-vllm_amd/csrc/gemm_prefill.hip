@@ -31,6 +31,7 @@ constexpr int kPK = 64;             // k per LDS stage
 constexpr int kPStage = kPM * kPK * 2; // bytes of one x stage in LDS
 constexpr int kPMT = kPM / 16;      // m-tiles per wave
 constexpr int kPNT = 4;             // n-tiles per wave
+constexpr int kWSlotBytes = 8 * 32 * 64 * 16;   // a workgroup's accumulators: 8 waves x 32 registers of 16 bytes x 64 lanes
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
@@ -59,6 +60,9 @@ struct PGemmArgs {
     // accumulators to partial[ks][m][n]; a second launch adds the slices and applies the epilogue
     int ksplit, ktps;
     float* partial;
+    // wide form: slots of kWSlotBytes, one per workgroup, for the accumulators of a tile that several
+    // workgroups cut along k between them (null: tiles are never cut inside the launch)
+    float* cut_ws;
 };
 
 #ifdef MV_GEMM_STAMP
@@ -80,14 +84,20 @@ static __device__ unsigned long long g_stamp[4 * 512];
 #ifdef MV_GEMM_WSTAMP
 // Wide form, tools/stamp_gemm_wide.py: wall-clock ticks (100 MHz) of wave 0 of workgroup kWStampBlock at
 // the top of every second k-tile and on either side of a tile's output stores; slot = tile-local
-// index + (nkt + 2) * tile.
-constexpr int kWStampBlock = 77;
+// index + 512 * piece (k-tiles 0, 2, .. then nkt, nkt + 1 for the two sides of the epilogue).
+#ifndef MV_WSTAMP_BLOCK
+#define MV_WSTAMP_BLOCK 77
+#endif
+constexpr int kWStampBlock = MV_WSTAMP_BLOCK;
 static __device__ unsigned long long g_wstamp[4096];
 #define MV_WSTAMP(i)                                                                         \
     do {                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                   \
-        const int si_ = (i) - g0 + tile_no * (nkt + 2);                                      \
-        if (blockIdx.x == kWStampBlock && threadIdx.x == 0 && si_ < 4096) g_wstamp[si_] = wall_clock64(); \
+        const int si_ = (i) - g0 + tile_no * 512;                                      \
+        if (blockIdx.x == kWStampBlock && threadIdx.x == 0 && si_ < 2048) {                   \
+            g_wstamp[si_] = wall_clock64();                                                  \
+            g_wstamp[2048 + si_] = clock64();   /* shader clock: the ratio of the two gives its frequency */ \
+        }                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                   \
     } while (0)
 #else
@@ -123,8 +133,18 @@ __device__ __forceinline__ float silu_mul_rounded_quick(float gate_acc, float up
 }
 template <int NT>
 __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_t (&acc)[NT][kPMT], int nt0,
-                                                int m0, int ks, int r, int q) {
+                                                int m0, int ks, int r, int q, const unsigned char* lower = nullptr,
+                                                int nlower = 0) {
     const bool sw = (a.flags & MV_GEMM_SWIGLU) != 0, of32 = (a.flags & MV_GEMM_OUT_F32) != 0;
+    // `lower`: this wave's 32 KiB in the first of `nlower` accumulator slots (8 slots apart) that hold
+    // the sums over the lower parts of k, register by register as they lie here; added in part order
+    const unsigned lane16 = (threadIdx.x & 63) * 16;
+    auto sum = [&](int i, int t) __attribute__((always_inline)) {
+        f32x4_t c = acc[i][t];
+        for (int e = 0; e < nlower; ++e)
+            c += *reinterpret_cast<const f32x4_t*>(lower + (size_t)e * 8 * kWSlotBytes + (i * 8 + t) * 1024 + lane16);
+        return c;
+    };
     if (a.partial) {
 #pragma unroll
         for (int t = 0; t < kPMT; ++t) {
@@ -133,7 +153,7 @@ __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_
             float* const row = a.partial + ((int64_t)ks * a.m + min(m, a.m - 1)) * a.n + nt0 * 16 + q * 4;
 #pragma unroll
             for (int i = 0; i < NT; ++i)
-                if (nt0 + i < a.nt && m < a.m) *reinterpret_cast<f32x4_t*>(row + i * 16) = acc[i][t];
+                if (nt0 + i < a.nt && m < a.m) *reinterpret_cast<f32x4_t*>(row + i * 16) = sum(i, t);
         }
         return;
     }
@@ -156,7 +176,7 @@ __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_
             uint32_t o[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const f32x4_t c = acc[i][t];
+                const f32x4_t c = sum(i, t);
                 const auto s0 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[0]), __float_as_uint(c[2]), false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[1]), __float_as_uint(c[3]), false, false);
                 o[i] = pack_bf16x2(silu_mul_rounded_quick(__uint_as_float(s0[1]), __uint_as_float(s0[0])),
@@ -190,7 +210,7 @@ __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_
             float* const row = reinterpret_cast<float*>(a.y) + (int64_t)min(m, a.m - 1) * a.ldy + nt0 * 16 + q * 4;
 #pragma unroll
             for (int i = 0; i < NT; ++i)
-                if (nt0 + i < a.nt && m < a.m) *reinterpret_cast<f32x4_t*>(row + i * 16) = acc[i][t];
+                if (nt0 + i < a.nt && m < a.m) *reinterpret_cast<f32x4_t*>(row + i * 16) = sum(i, t);
         }
         return;
     }
@@ -227,8 +247,8 @@ __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_
             if (nt0 + i >= a.nt) continue;  // uniform
             if (i + 1 < NT && pairs && nt0 + i + 1 < a.nt) {
                 constexpr int kLast = NT - 1;
-                const uint2 p0 = rounded(acc[i][t], bias + i * 16, res + i * 16);
-                const uint2 p1 = rounded(acc[i + 1 < NT ? i + 1 : kLast][t], bias + (i + 1) * 16, res + (i + 1) * 16);
+                const uint2 p0 = rounded(sum(i, t), bias + i * 16, res + i * 16);
+                const uint2 p1 = rounded(sum(i + 1 < NT ? i + 1 : kLast, t), bias + (i + 1) * 16, res + (i + 1) * 16);
                 const auto rx = __builtin_amdgcn_permlane16_swap(p0.x, p1.x, false, false);
                 const auto ry = __builtin_amdgcn_permlane16_swap(p0.y, p1.y, false, false);
                 if (m < a.m)
@@ -237,7 +257,7 @@ __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_
 #pragma unroll
                 for (int ii = i; ii < i + 2 && ii < NT; ++ii)
                     if (nt0 + ii < a.nt) {  // uniform
-                        const uint2 o = rounded(acc[ii][t], bias + ii * 16, res + ii * 16);
+                        const uint2 o = rounded(sum(ii, t), bias + ii * 16, res + ii * 16);
                         if (m < a.m) *reinterpret_cast<uint2*>(row + ii * 16 + q * 4) = o;
                     }
             }
@@ -435,6 +455,43 @@ __global__ __launch_bounds__(256, 2) void gemm_prefill_kernel(PGemmArgs a) {
 constexpr int kWM = 256, kWN = 256;
 constexpr int kWXSlot = 32768, kWWSlot = 16384;
 constexpr int kWLds = 3 * kWXSlot + 4 * kWWSlot;
+constexpr int kWMaxGrid = 1024;
+// one counter per XCD and left-over tile; zero between launches (the last part resets it)
+static __device__ unsigned g_wide_cut_count[kWMaxGrid];
+
+// Which XCD a workgroup of a one-dimensional grid runs on, for the host to check that workgroups 8
+// apart share one (the parts of a cut tile synchronise through that XCD's L2 alone).
+static __device__ unsigned g_wide_xcc[kWMaxGrid];
+__global__ __launch_bounds__(512, 1) void wide_xcc_probe_kernel() {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    if (threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wide_xcc[blockIdx.x] = (xcc & 0xf) + 1;
+        lds[0] = (unsigned char)xcc;   // the LDS allocation is what places one workgroup per CU, as in the real launch
+    }
+}
+
+// Parts a left-over tile is cut into along k: at most as many as there are workgroups per left-over
+// tile, each a whole number of 64-wide stages and at least 8 k-tiles long.  A part costs its share of
+// the tile; every part more costs the last one about an eighth of a tile (it reads that part's 256 KiB of
+// sums inside its epilogue, measured 8 us per part against 100 us tiles), so the count that
+// makes 1/p + (p - 1)/8 smallest is taken - two to four in practice.
+__host__ __device__ inline int wide_cut_parts(int rest, int wgs, int nkt) {
+    if (rest <= 0) return 1;
+    const int most = wgs / rest < 8 ? wgs / rest : 8;
+    int best = 1;
+    float best_cost = 1.0f;
+    for (int p = 2; p <= most; ++p) {
+        if (nkt % (2 * p) != 0 || nkt / p < 8) continue;
+        const float cost = 1.0f / p + 0.125f * (p - 1);
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = p;
+        }
+    }
+    return best;
+}
 
 // One wave's share of a tile: NT n-tiles from strip `wcol` of a block that is `width` strips wide.
 template <int NT>
@@ -446,20 +503,24 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
     const int lane = threadIdx.x & 63;
     const int r = lane & 15, q = lane >> 4;
 
-    // Tile ids of this workgroup: blockIdx.x, + gridDim.x, ... (the grid is one workgroup per CU, or
-    // one per tile id).  A workgroup that has a further tile never drains its pipeline between the
-    // two: the copies issued during the last four k-tiles of a tile already bring the first weight
-    // tiles and x stages of the next one into the ring slots that fall free, the output stores of the
-    // finished tile are left in flight, and the accumulators start again from zero.  A round of tiles
-    // otherwise costs about 20 us that no MFMA covers (every CU of the chip filling its rings from
-    // cold at the same moment, and every CU waiting for its output stores before the next workgroup
-    // may start): measured on one round, 0.745 us per k-tile + 22.8 us.
+    // The grid is one workgroup per CU (or one per tile, with MVLLM_PREFILL_PERSIST=0).  A workgroup
+    // that has a further tile never drains its pipeline between the two: the copies issued during the
+    // last four k-tiles of a tile already bring the first weight tiles and x stages of the next one
+    // into the ring slots that fall free, the output stores of the finished tile are left in flight,
+    // and the accumulators start again from zero.
     //
-    // id -> tile.  An XCD (id mod 8; the stride is a multiple of 8) owns a contiguous range of
-    // n-blocks and walks it in bands of `mband` m-blocks: m fastest inside the band, then n, then the
-    // next band - so the 32 workgroups resident on the XCD at one time are mband x 32/mband tiles
-    // (8 x 4 at 2048 tokens and more) rather than one long column, and the operand rows they pull
-    // through that XCD's L2 together are as few as 32 tiles allow.
+    // Tiles of an XCD (blockIdx mod 8; it owns a contiguous range of n-blocks) are numbered in bands
+    // of `mband` m-blocks: m fastest inside the band, then n, then the next band - so the workgroups
+    // resident on the XCD at one time hold mband x W/mband tiles (8 x 4 at 2048 tokens and more)
+    // rather than one long column, and the operand rows they pull through that XCD's L2 together are
+    // as few as that many tiles allow.  With W workgroups on the XCD and T tiles, workgroup j takes
+    // tiles j, j + W, ... of the first W floor(T / W); the R = T mod W tiles left over would keep R
+    // workgroups busy for a whole tile while the others wait, so where R <= W / 2 each of them is cut
+    // along k into p = floor(W / R) parts (wide_cut_parts), one per workgroup.  The p - 1 workgroups
+    // with the lower parts take them first, write their accumulators to their slot of `cut_ws` and
+    // count themselves in; the one with the last part - the highest numbered, so the ones it waits
+    // for were dispatched before it - takes it after its whole tiles, starts its accumulators from
+    // the sum of those slots and runs the epilogue.
     //
     // Copy sources of this wave in a tile: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles
     // likewise.  Every copy is addressed as a wave-uniform 64-bit base (scalar registers) plus a
@@ -468,24 +529,57 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
     struct Tile {
         const unsigned char* wbase[2];
         const unsigned char* xbase[2];
-        unsigned xlane[4];
+        unsigned xlim[2];   // byte offset of the last row of x inside each of the wave's two m-tiles
         int ks, m0, ntb;
+        int nkt;          // k-tiles of this piece of work (a slice, or a part of one)
+        int part, parts;  // part of a cut tile (parts == 1: the whole tile or slice)
+        int rest;         // cut tile: its number among the XCD's left-over tiles
     };
-    const int tiles = 8 * a.nb_per_xcd * a.mblocks;
-    const int total = tiles * a.ksplit, stride = gridDim.x;
-    const int nkt = a.ktps, nstage = nkt >> 1;
-    auto decode = [&](int id, Tile& tl) __attribute__((always_inline)) -> bool {
-        const int ks = id / tiles, bid = id - ks * tiles;   // k-slice (see the host side), tile
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int per_band = a.mband * a.nb_per_xcd;
-        const int band = min(idx / per_band, (a.mblocks - 1) / a.mband);
+    const int xcd = blockIdx.x & 7, wj = blockIdx.x >> 3, wgs = gridDim.x >> 3;
+    const int owned = max(0, min(a.nb_per_xcd, a.nblocks - xcd * a.nb_per_xcd));   // n-blocks of this XCD
+    const int per_slice = owned * a.mblocks;
+    const int ntiles = per_slice * a.ksplit;
+    const int full = ntiles / wgs, rest = ntiles - full * wgs;
+    const int parts = a.cut_ws && full > 0 ? wide_cut_parts(rest, wgs, a.ktps) : 1;
+    // An x copy moves rows (lane >> 3) and 8 + (lane >> 3) of an m-tile, 16 bytes per lane: the chunk
+    // that lives at position lane & 7 of the row in LDS.  Rows past the end of x repeat its last row.
+    const unsigned row_bytes = (unsigned)(a.ldx * 2);
+    const unsigned xrow = (unsigned)(lane >> 3) * row_bytes;
+    const unsigned xchunk = (unsigned)(((lane & 7) ^ ((lane >> 4) & 7)) * 16);
+    auto x_lane = [&](const Tile& tl, int j) __attribute__((always_inline)) {   // j: m-tile 2 wid + (j >> 1), rows 8 (j & 1) ..
+        return min(xrow + (unsigned)(j & 1) * 8u * row_bytes, tl.xlim[j >> 1]) + (xchunk ^ ((unsigned)(j & 1) * 64u));
+    };
+    // piece of work number n of this workgroup -> tile; false past the last one
+    auto decode = [&](int n, Tile& tl) __attribute__((always_inline)) -> bool {
+        // a workgroup with a piece of the left-over round takes it first - except the last part of a
+        // cut tile, which comes after the workgroup's whole tiles: by then the lower parts are done
+        const bool has_rest = wj < rest * parts;
+        const int my_part = wj - (wj / parts) * parts;
+        const bool last_part = has_rest && parts > 1 && my_part == parts - 1;
+        const int rest_at = last_part ? full : 0;
+        int index, part = 0;
+        const bool is_rest = has_rest && n == rest_at;
+        if (is_rest) {
+            index = full * wgs + wj / parts;
+            part = my_part;
+        } else {
+            const int round = n - (has_rest && n > rest_at ? 1 : 0);
+            if (round >= full) return false;
+            index = wj + round * wgs;
+        }
+        const bool is_cut = is_rest && parts > 1;
+        const int ks = index / per_slice, idx = index - ks * per_slice;   // k-slice (see the host side), tile
+        const int per_band = a.mband * owned;
+        const int band = idx / per_band;
         const int rows = min(a.mband, a.mblocks - band * a.mband);
         const int j = idx - band * per_band;
-        const int nbl = j / rows;
-        const int nb = xcd * a.nb_per_xcd + nbl;
+        const int nb = xcd * a.nb_per_xcd + j / rows;
         const int mb = band * a.mband + j % rows;
-        if (nb >= a.nblocks || nbl >= a.nb_per_xcd) return false;
-        const int kt0 = ks * a.ktps;
+        tl.nkt = is_cut ? a.ktps / parts : a.ktps;
+        tl.part = part;
+        tl.parts = is_cut ? parts : 1;
+        tl.rest = wj / parts;
+        const int kt0 = ks * a.ktps + part * tl.nkt;
         tl.ks = ks;
         tl.m0 = mb * kWM;
         tl.ntb = nb * width;
@@ -493,29 +587,20 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
         for (int j = 0; j < 2; ++j)
             tl.wbase[j] = reinterpret_cast<const unsigned char*>(a.w + ((int64_t)min(tl.ntb + 2 * wid + j, a.nt - 1) * a.kt + kt0) * 64);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int first = min(tl.m0 + (2 * wid + (j >> 1)) * 16, a.m - 1);   // first row of the m-tile (clamped)
-            const int row = (j & 1) * 8 + (lane >> 3);                             // row of the m-tile
-            const int c = (lane & 7) ^ ((row >> 1) & 7);                           // the chunk that lives at position lane & 7
-            const int grow = min(tl.m0 + (2 * wid + (j >> 1)) * 16 + row, a.m - 1);
-            if ((j & 1) == 0) tl.xbase[j >> 1] = reinterpret_cast<const unsigned char*>(a.x + (int64_t)first * a.ldx + kt0 * 32);
-            tl.xlane[j] = (unsigned)(((int64_t)(grow - first) * a.ldx + c * 8) * 2);
+        for (int j = 0; j < 2; ++j) {
+            const int first = min(tl.m0 + (2 * wid + j) * 16, a.m - 1);   // first row of the m-tile (clamped)
+            tl.xbase[j] = reinterpret_cast<const unsigned char*>(a.x + (int64_t)first * a.ldx + kt0 * 32);
+            tl.xlim[j] = (unsigned)min(15, a.m - 1 - first) * row_bytes;
         }
         return true;
     };
     Tile cur, nxt;
-    int id = blockIdx.x;
-    while (id < total && !decode(id, cur)) id += stride;
-    if (id >= total) return;
-    // the tile after `from`; with none left `nxt` repeats `cur`, whose first k-tiles are then fetched
-    // once more into slots nobody reads (the copy counts per k-tile stay fixed)
-    auto following = [&](int from) __attribute__((always_inline)) {
-        int n = from + stride;
-        while (n < total && !decode(n, nxt)) n += stride;
-        if (n >= total) nxt = cur;
-        return n;
-    };
-    int nid = following(id);
+    if (!decode(0, cur)) return;
+    // with no piece left `nxt` repeats `cur`, whose first k-tiles are then fetched once more into
+    // slots nobody reads (the copy counts per k-tile stay fixed)
+    int piece = 0;
+    bool more = decode(1, nxt);
+    if (!more) nxt = cur;
     const unsigned wlane = lane * 16;
     const unsigned x_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)xring;
     const unsigned w_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wring;
@@ -523,7 +608,7 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      : : "v"(lane_off), "s"(base), "s"(dst) : "memory");
     };
-    // the ring fill in front of a workgroup's first tile (a slice has at least 8 k-tiles)
+    // the ring fill in front of a workgroup's first piece (a piece has at least 8 k-tiles)
     auto copy_w = [&](int kt, int slot) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -532,7 +617,7 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
     auto copy_x = [&](int st, int slot) {
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            copy(cur.xbase[j >> 1] + st * 128, cur.xlane[j], x_lds + slot * kWXSlot + (2 * wid + (j >> 1)) * 2048 + (j & 1) * 1024);
+            copy(cur.xbase[j >> 1] + st * 128, x_lane(cur, j), x_lds + slot * kWXSlot + (2 * wid + (j >> 1)) * 2048 + (j & 1) * 1024);
     };
     // fragment reads: per-lane byte offsets inside a slot
     const int xoff0 = (wm * 8) * 2048 + r * 128 + (((0 + q) ^ ((r >> 1) & 7)) * 16);   // kk = 0
@@ -587,17 +672,17 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
         // pieces of this k-tile in issue order: on odd k-tiles the four x pieces first
         const int nx = odd ? 4 : 0;
         if (p < nx) {
-            const int s3 = (kt >> 1) + 3, slot = (g >> 1) % 3;
+            const int s3 = (kt >> 1) + 3, slot = (g >> 1) % 3, nstage = cur.nkt >> 1;
             const bool over = s3 >= nstage;
             const unsigned char* base = over ? nxt.xbase[p >> 1] : cur.xbase[p >> 1];
             const int st = over ? s3 - nstage : s3;
-            copy(base + st * 128, over ? nxt.xlane[p] : cur.xlane[p],
+            copy(base + st * 128, x_lane(over ? nxt : cur, p),
                  x_lds + slot * kWXSlot + (2 * wid + (p >> 1)) * 2048 + (p & 1) * 1024);
         } else if (p < nx + 2) {
             const int j = p - nx, k4 = kt + 4;
-            const bool over = k4 >= nkt;
+            const bool over = k4 >= cur.nkt;
             const unsigned char* base = over ? nxt.wbase[j] : cur.wbase[j];
-            const int ktc = over ? k4 - nkt : k4;
+            const int ktc = over ? k4 - cur.nkt : k4;
             copy(base + (int64_t)ktc * 1024, wlane, w_lds + (g & 3) * kWWSlot + (2 * wid + j) * 1024);
         }
     };
@@ -637,8 +722,9 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
 #endif
     };
     [[maybe_unused]] int tile_no = 0;
-    for (int g0 = 0;; g0 += nkt) {
-        for (int kt = 0; kt < nkt; kt += 2) {   // a slice is a multiple of 64 k (checked on the host)
+    for (int g0 = 0;;) {
+        const int nkt = cur.nkt;
+        for (int kt = 0; kt < cur.nkt; kt += 2) {   // a piece is a multiple of 64 k (checked on the host)
             MV_WSTAMP(g0 + kt);
             ktile(wA, xA, wB, xB, g0 + kt, kt, false);
             ktile(wB, xB, wA, xA, g0 + kt + 1, kt + 1, true);
@@ -651,16 +737,67 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
 #pragma unroll
             for (int t = 0; t < kPMT; ++t) asm volatile("" : : "v"(acc[i][t]));
 #else
-        if (cur.ntb + wcol < a.nt) store_wave_tile<NT>(a, acc, cur.ntb + wcol, cur.m0 + wm * 128, cur.ks, r, q);
+        if (cur.parts > 1 && cur.part + 1 < cur.parts) {
+            // a lower part of a cut tile: the accumulators as they lie in the registers (1 KiB per
+            // register and wave), then one count per workgroup once every wave's stores are visible
+            // (a wave-uniform base and a 32-bit lane offset: per-lane 64-bit addresses for 32 stores
+            // that lie further apart than an instruction's offset field reaches cost 64 registers)
+            size_t my_offset = (size_t)blockIdx.x * kWSlotBytes + (size_t)wid * 32768;
+            asm volatile("" : "+s"(my_offset));   // formed here: 32 addresses hoisted out of the loop over pieces would be held, or spilled, throughout
+            unsigned char* const mine = reinterpret_cast<unsigned char*>(a.cut_ws) + my_offset;
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int t = 0; t < kPMT; ++t)
+                    *reinterpret_cast<f32x4_t*>(mine + (i * 8 + t) * 1024 + wlane) = acc[i][t];
+            // The parts of a tile run on one XCD (the host has checked that workgroups 8 apart do) and so
+            // meet in one L2: a store is counted off vmcnt once it is there, the counter lives there,
+            // and the reader has never touched these lines, so nothing needs writing back or
+            // invalidating - a device-wide release here writes back the whole L2 and the matching
+            // acquire empties it for every workgroup of the XCD (measured: 227 -> 305 us).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_fetch_add(&g_wide_cut_count[xcd * wgs + cur.rest], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // The last part of a cut tile adds the lower parts as it runs the epilogue.  Their
+            // workgroups took them first and were dispatched before this one, so the wait is over
+            // before it begins unless this launch shares the GPU; the counter is left at zero for the
+            // next launch.  (Adding them into the accumulators here instead, under this condition,
+            // makes the compiler keep a second set of the 128 registers and move and spill between the
+            // two at every tile: with the path compiled in and never taken, 4096^3 119 -> 144 us.)
+            const unsigned char* lower = nullptr;
+            int nlower = 0;
+            if (cur.parts > 1) {
+                if (threadIdx.x == 0) {
+                    unsigned* const count = &g_wide_cut_count[xcd * wgs + cur.rest];
+                    for (int spin = 0; spin < (1 << 22) &&
+                                       __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(cur.parts - 1);
+                         ++spin)
+                        __builtin_amdgcn_s_sleep(16);
+                    __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+                asm volatile("" ::: "memory");
+                lower = reinterpret_cast<const unsigned char*>(a.cut_ws) + (size_t)(((cur.rest * cur.parts) << 3) | xcd) * kWSlotBytes +
+                        (size_t)wid * 32768;
+                nlower = cur.parts - 1;
+            }
+            if (cur.ntb + wcol < a.nt)
+                store_wave_tile<NT>(a, acc, cur.ntb + wcol, cur.m0 + wm * 128, cur.ks, r, q, lower, nlower);
+        }
 #endif
         MV_WSTAMP(g0 + nkt + 1);
-        if (nid >= total) break;
+        if (!more) break;
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int t = 0; t < kPMT; ++t) acc[i][t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        g0 += nkt;
         cur = nxt;
-        nid = following(nid);
+        ++piece;
+        more = decode(piece + 1, nxt);
+        if (!more) nxt = cur;
         ++tile_no;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land in LDS after this workgroup is gone
@@ -758,21 +895,92 @@ struct PrefillPlan {
     int ks;
     int strips;   // wide form: 16-column strips per tile (16, 14 or 12)
 };
-static int wide_tile_strips(int m, int n) {
+// MVLLM_PREFILL_PERSIST = 0 launches one wide-form workgroup per tile instead of one per CU (read once)
+static bool wide_persistent() {
+    static const bool on = [] {
+        const char* e = getenv("MVLLM_PREFILL_PERSIST");
+        return !(e && *e) || atoi(e) != 0;
+    }();
+    return on;
+}
+// workgroups of a wide-form launch over `ids` tile slots (8 x the slots of the fullest XCD)
+static long wide_grid(long ids) {
+    const long resident = std::max(8, num_cus() / 8 * 8);
+    return wide_persistent() ? std::min(ids, resident) : ids;
+}
+// MVLLM_PREFILL_CUT = 0: left-over tiles are never cut along k inside the launch (read once)
+static int g_debug_cut = -1, g_debug_strips = -1;   // mv_debug_prefill_options: overrides for A/B runs in one process
+static bool wide_cut_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MVLLM_PREFILL_CUT");
+        return !(e && *e) || atoi(e) != 0;
+    }();
+    return (g_debug_cut >= 0 ? g_debug_cut != 0 : on) && wide_persistent();
+}
+// True once a probe launch on this device has shown that workgroups b and b + 8 k of a grid of one
+// workgroup per CU run on the same XCD.  Probed on the first call with a stream that is not being
+// captured (the probe synchronises that stream); until then, and if the check fails, no tile is cut.
+static bool wide_same_xcd(hipStream_t stream) {
+    static int state[64] = {0};   // 0 unknown, 1 holds, -1 does not
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (state[dev] != 0) return state[dev] > 0;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+    static LdsOptIn lds_done;
+    const int grid = (int)std::min<long>(kWMaxGrid, wide_grid(kWMaxGrid));
+    static unsigned host[kWMaxGrid];
+    state[dev] = -1;
+    if (ensure_dynamic_lds((const void*)wide_xcc_probe_kernel, kWLds, lds_done) != MV_OK) return false;
+    hipLaunchKernelGGL(wide_xcc_probe_kernel, dim3(grid), dim3(512), kWLds, stream);
+    if (hipStreamSynchronize(stream) != hipSuccess) return false;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wide_xcc), sizeof(unsigned) * grid) != hipSuccess) return false;
+    for (int b = 0; b < grid; ++b)
+        if (host[b] == 0 || host[b] != host[b & 7]) return false;
+    state[dev] = 1;
+    return true;
+}
+// Does any XCD of an unsliced wide-form launch cut its left-over tiles?  (Then the launch needs one
+// accumulator slot per workgroup.)
+static bool wide_cuts(int mblocks, int nblocks, int kt) {
+    if (!wide_cut_enabled()) return false;
+    const int per_xcd = (nblocks + 7) / 8;
+    const long grid = wide_grid(8L * per_xcd * mblocks);
+    const int wgs = (int)(grid / 8);
+    for (int x = 0; x < 8; ++x) {
+        const int owned = std::max(0, std::min(per_xcd, nblocks - x * per_xcd));
+        const int ntiles = owned * mblocks;
+        if (ntiles >= wgs && wide_cut_parts(ntiles % wgs, wgs, kt) > 1) return true;
+    }
+    return false;
+}
+// Length of an unsliced wide-form launch in whole tiles (the fullest XCD sets it)
+static double wide_rounds(int mblocks, int nblocks, int kt) {
+    const int per_xcd = (nblocks + 7) / 8;
+    const long grid = wide_grid(8L * per_xcd * mblocks);
+    const int wgs = (int)(grid / 8);
+    const int ntiles = per_xcd * mblocks;
+    const int rest = ntiles % wgs;
+    const int parts = wide_cut_enabled() && ntiles >= wgs ? wide_cut_parts(rest, wgs, kt) : 1;
+    // a cut costs a quarter of a tile beyond the parts themselves (the slots written and read, two
+    // epilogues and a second ring fill per tile: 4096 x 6144 x 4096 in 256-column tiles, 2 rounds
+    // 196 us, 1.5 rounds 178)
+    return ntiles / wgs + (rest == 0 ? 0.0 : parts == 1 ? 1.0 : 1.0 / parts + 0.125 * (parts - 1) + 0.25);
+}
+static int wide_tile_strips(int m, int n, int kt) {
     static const int forced = [] {
         const char* e = getenv("MVLLM_PREFILL_WIDE_STRIPS");
         return e && *e ? atoi(e) : 0;
     }();
+    if (g_debug_strips == 12 || g_debug_strips == 14 || g_debug_strips == 16) return g_debug_strips;
     if (forced == 12 || forced == 14 || forced == 16) return forced;
-    const long mblocks = (m + kWM - 1) / kWM;
-    const long nt = n / 16;
-    const int per_xcd = std::max(1, num_cus() / 8);
+    const int mblocks = (m + kWM - 1) / kWM;
+    const int nt = n / 16;
     int best = 16;
     double best_cost = 1e30;
     for (int w = 16; w >= 12; w -= 2) {
-        const long nblocks = (nt + w - 1) / w;
-        const long rounds = (((nblocks + 7) / 8) * mblocks + per_xcd - 1) / per_xcd;
-        const double cost = (double)rounds * w * (w == 16 ? 1.0 : w == 14 ? 1.10 : 1.12);
+        const int nblocks = (nt + w - 1) / w;
+        const double cost = wide_rounds(mblocks, nblocks, kt) * w * (w == 16 ? 1.0 : w == 14 ? 1.10 : 1.12);
         if (cost < best_cost) {
             best_cost = cost;
             best = w;
@@ -790,16 +998,27 @@ static PrefillPlan prefill_plan(int m, int n, int kt) {
     const long tiles = (long)((m + kWM - 1) / kWM) * ((n + kWN - 1) / kWN);
     const int cus = num_cus();
     if (forced < 0 && kt >= 128 && kt % 4 == 0 && 8 * tiles >= 3L * cus && 2 * tiles <= cus) return {true, 2, 16};
-    if (narrow_ks == 1 && (forced == 1 || 2 * tiles >= cus)) return {true, 1, wide_tile_strips(m, n)};
+    if (narrow_ks == 1 && (forced == 1 || 2 * tiles >= cus)) return {true, 1, wide_tile_strips(m, n, kt)};
     return {false, narrow_ks, 16};
 }
 }  // namespace mv
 
+// Experiments only (tools/ab_gemm_prefill.py): whether left-over tiles are cut (0 / 1) and the tile width
+// in strips (12 / 14 / 16) for the calls that follow; -1 returns a choice to the environment and the plan.
+extern "C" void mv_debug_prefill_options(int cut, int strips) {
+    mv::g_debug_cut = cut;
+    mv::g_debug_strips = strips;
+}
+
 extern "C" size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k) {
     using namespace mv;
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
-    const int ks = prefill_plan(m, n, k / 32).ks;
-    return ks > 1 ? (size_t)ks * m * n * sizeof(float) : 0;
+    const PrefillPlan plan = prefill_plan(m, n, k / 32);
+    if (plan.ks > 1) return (size_t)plan.ks * m * n * sizeof(float);
+    if (!plan.wide) return 0;
+    const int mblocks = (m + kWM - 1) / kWM, nblocks = (n / 16 + plan.strips - 1) / plan.strips;
+    if (!wide_cuts(mblocks, nblocks, k / 32)) return 0;
+    return (size_t)wide_grid(8L * ((nblocks + 7) / 8) * mblocks) * kWSlotBytes;
 }
 
 extern "C" int mv_gemm_prefill_form(int m, int n, int k) {
@@ -855,6 +1074,7 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
     const PrefillPlan plan = prefill_plan(m, n, a.kt);
     a.ksplit = plan.ks;
     a.partial = nullptr;
+    a.cut_ws = nullptr;
     bool wide = plan.wide;
     if (a.ksplit > 1) {
         const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
@@ -884,14 +1104,15 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
         }
         const long ids = 8L * a.nb_per_xcd * a.mblocks * a.ksplit;
         if (ids > 0x7fffffffL) return MV_ERR_UNSUPPORTED;
-        // one workgroup per CU walks the tile ids with that stride (a multiple of 8: an id keeps its
-        // XCD); MVLLM_PREFILL_PERSIST = 0 launches one workgroup per id instead (read once)
-        static const bool persist = [] {
-            const char* e = getenv("MVLLM_PREFILL_PERSIST");
-            return !(e && *e) || atoi(e) != 0;
-        }();
-        const long resident = std::max(8, num_cus() / 8 * 8);
-        const long wgrid = persist ? std::min(ids, resident) : ids;
+        // one workgroup per CU takes its share of every XCD's tiles (a multiple of 8 workgroups: a
+        // workgroup's XCD is its number mod 8)
+        const long wgrid = wide_grid(ids);
+        // left-over tiles are cut along k inside the launch when the caller's workspace holds a slot per
+        // workgroup; without it they are taken whole (slower, same result class)
+        if (a.ksplit == 1 && wgrid <= kWMaxGrid && wide_cuts(a.mblocks, a.nblocks, a.kt) && workspace &&
+            aligned16(workspace) && workspace_bytes >= (size_t)wgrid * kWSlotBytes &&
+            wide_same_xcd((hipStream_t)stream))
+            a.cut_ws = (float*)workspace;
         if (strips == 12)
             hipLaunchKernelGGL((gemm_prefill_wide_kernel<3, 3>), dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
         else if (strips == 14)

@@ -138,6 +138,73 @@ def test_gemm_prefill_wide_form(mv, m, n, k, mode):
     assert float((ulp_diff(got, want) == 0).float().mean()) > 0.98
 
 
+@pytest.mark.parametrize("m,n,k,mode,strips", [
+    (3072, 6144, 1024, "bias", 12),        # 48 tiles per XCD on 32 CUs: the 16 left over in two parts each
+    (2560, 6144, 3072, "residual", 12),    # 40 tiles per XCD: the 8 left over in three parts each
+    (4096, 6144, 2048, "swiglu", 16),      # the fused activation behind a cut tile
+    (2300, 7168, 1024, "f32", 14),         # a ragged last m-block, fp32 out
+    (3000, 7168, 1536, "residual", 16),    # 28 n-blocks: the eighth XCD owns none
+])
+def test_gemm_prefill_wide_form_cuts_left_over_tiles(mv, m, n, k, mode, strips):
+    """With more tiles than CUs and a remainder of at most half a round, the left-over tiles are cut
+    along k between workgroups inside the launch (the last part adds the others' sums in its
+    epilogue).  Checked against the oracle, against the same launch with the cut switched off, and
+    twice in a row (the parts count themselves in through counters that must be back at zero)."""
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    if _cus() != 256:
+        pytest.skip("the cases are laid out for 32 CUs per XCD")
+    L = nv.lib()
+    x, w, g = _mk(m, n, k, seed=m + n + k + strips, scale=0.03)
+    bias = torch.randn(n, generator=g).to(torch.bfloat16) if mode == "bias" else None
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16) if mode == "residual" else None
+    swiglu = mode == "swiglu"
+    sw = (StreamedWeight.from_up_gate(w[:n // 2].to(DEV), w[n // 2:].to(DEV)) if swiglu
+          else StreamedWeight.from_linear(w.to(DEV)))
+    ncols = sw.out_features
+    dt = torch.float32 if mode == "f32" else torch.bfloat16
+
+    def run():
+        yb = torch.full((m, ncols + 32), 7.0, dtype=dt, device=DEV)
+        gemm_prefill(x.to(DEV), sw, yb[:, :ncols], bias=None if bias is None else bias.to(DEV),
+                     residual=None if res is None else res.to(DEV), swiglu=swiglu)
+        assert torch.all(yb[:, ncols:] == 7.0), "wrote past the row"
+        return yb[:, :ncols].cpu()
+
+    try:
+        L.mv_debug_prefill_options(1, strips)
+        assert L.mv_gemm_prefill_workspace_bytes(m, n, k) == 256 * 256 * 1024, "meant to cut its left-over tiles"
+        cut, again = run(), run()
+        L.mv_debug_prefill_options(0, strips)
+        assert L.mv_gemm_prefill_workspace_bytes(m, n, k) == 0
+        whole = run()
+    finally:
+        L.mv_debug_prefill_options(-1, -1)
+    assert torch.equal(cut, again), "the second launch differs from the first"
+    want32 = x.float() @ w.float().t()
+    scale = max(1.0, want32.abs().max().item())
+    if mode == "f32":
+        assert (cut - want32).abs().max().item() <= 1e-4 * scale
+        assert (cut - whole).abs().max().item() <= 1e-4 * scale
+        return
+    if swiglu:
+        want = swiglu_ref(linear_ref(x, w))
+        assert_close_bf16(cut, want, atol=1e-3, rtol=2 ** -6, what="cut tiles, fused swiglu")
+        assert_close_bf16(cut, whole, atol=1e-3, rtol=2 ** -6, what="cut vs whole tiles, fused swiglu")
+    else:
+        t0 = linear_ref(x, w).float()
+        t1 = linear_ref(x, w, bias).float()
+        want = t1 if res is None else (t1 + res.float()).to(torch.bfloat16).float()
+        mag = torch.maximum(torch.maximum(t0.abs(), t1.abs()), want.abs())
+        for name, ref in (("oracle", want), ("whole tiles", whole.float())):
+            err = (cut.float() - ref).abs()
+            assert bool((err <= 1e-3 + 2 ** -6 * mag).all()), f"{mode} vs {name}: max err {err.max().item():.3e}"
+        want = want.to(torch.bfloat16)
+    assert float((ulp_diff(cut, want) == 0).float().mean()) > 0.98
+    assert float((ulp_diff(cut, whole) == 0).float().mean()) > 0.98
+
+
 def test_gemm_prefill_agrees_with_single_token_kernel(mv):
     """Same weights, same rows: the two kernels differ only in fp32 summation order."""
     from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill, wgemm

@@ -28,17 +28,21 @@ buf = np.zeros(4096, dtype=np.uint64)
 lib = nv.lib()
 lib.mv_debug_read_wide_stamps.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
 assert lib.mv_debug_read_wide_stamps(buf.ctypes.data, buf.nbytes) == 0
-nkt = K // 32
-per = nkt + 2
+wg = int(os.environ.get("WG", "77"))
 t0 = int(buf[0])
-for tile in range(16):
-    s = buf[tile * per: (tile + 1) * per].astype(np.int64)
-    if s[0] == 0 and tile:
+last = max(i for i in range(2048) if buf[i])
+print(f"shader clock over the workgroup's run: {(int(buf[2048 + last]) - int(buf[2048])) / ((int(buf[last]) - t0) / 100.0) / 1e3:.3f} GHz")
+prev_end = None
+for piece in range(4):
+    s = buf[piece * 512: (piece + 1) * 512].astype(np.int64)
+    if s[0] == 0:
         break
+    nz = [i for i in range(512) if s[i]]
+    nkt = nz[-1] - 1                      # the last two stamps are nkt and nkt + 1
     tops = s[0:nkt:2]
-    nxt = int(buf[(tile + 1) * per]) if (tile + 1) * per < 4096 else 0
-    gap = (nxt - int(s[nkt + 1])) / 100.0 if nxt else float("nan")
     d = np.diff(tops) / 100.0
-    print(f"tile {tile}: starts {(int(s[0]) - t0) / 100.0:8.2f} us; k-tiles {(int(s[nkt]) - int(s[0])) / 100.0:7.2f} us "
+    gap = "" if prev_end is None else f"; {(int(s[0]) - prev_end) / 100.0:5.2f} us after the previous epilogue"
+    print(f"piece {piece}: {nkt} k-tiles, starts {(int(s[0]) - t0) / 100.0:8.2f} us{gap}; k-tiles {(int(s[nkt]) - int(s[0])) / 100.0:7.2f} us "
           f"(pairs: first 4 {np.round(d[:4], 2)}, median {np.median(d):.2f}, last 4 {np.round(d[-4:], 2)}); "
-          f"stores {(int(s[nkt + 1]) - int(s[nkt])) / 100.0:6.2f} us; to next top {gap:6.2f} us")
+          f"epilogue {(int(s[nkt + 1]) - int(s[nkt])) / 100.0:6.2f} us")
+    prev_end = int(s[nkt + 1])
