@@ -137,12 +137,18 @@ __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_
                                                 int nlower = 0) {
     const bool sw = (a.flags & MV_GEMM_SWIGLU) != 0, of32 = (a.flags & MV_GEMM_OUT_F32) != 0;
     // `lower`: this wave's 32 KiB in the first of `nlower` accumulator slots (8 slots apart) that hold
-    // the sums over the lower parts of k, register by register as they lie here; added in part order
+    // the sums over the lower parts of k, register by register as they lie here; added in part order.
+    // They were written by other workgroups of this launch: read with sc1 loads (served by L2 or
+    // memory, never by this CU's L1), the loads of one row of tiles in flight together.
     const unsigned lane16 = (threadIdx.x & 63) * 16;
     auto sum = [&](int i, int t) __attribute__((always_inline)) {
         f32x4_t c = acc[i][t];
-        for (int e = 0; e < nlower; ++e)
-            c += *reinterpret_cast<const f32x4_t*>(lower + (size_t)e * 8 * kWSlotBytes + (i * 8 + t) * 1024 + lane16);
+        for (int e = 0; e < nlower; ++e) {
+            f32x4_t part;
+            asm volatile("global_load_dwordx4 %0, %1, %2 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=v"(part) : "v"(lane16), "s"(lower + (size_t)e * 8 * kWSlotBytes + (i * 8 + t) * 1024) : "memory");
+            c += part;
+        }
         return c;
     };
     if (a.partial) {
@@ -153,7 +159,7 @@ __device__ __forceinline__ void store_wave_tile(const PGemmArgs& a, const f32x4_
             float* const row = a.partial + ((int64_t)ks * a.m + min(m, a.m - 1)) * a.n + nt0 * 16 + q * 4;
 #pragma unroll
             for (int i = 0; i < NT; ++i)
-                if (nt0 + i < a.nt && m < a.m) *reinterpret_cast<f32x4_t*>(row + i * 16) = sum(i, t);
+                if (nt0 + i < a.nt && m < a.m) *reinterpret_cast<f32x4_t*>(row + i * 16) = acc[i][t];
         }
         return;
     }
@@ -459,19 +465,6 @@ constexpr int kWMaxGrid = 1024;
 // one counter per XCD and left-over tile; zero between launches (the last part resets it)
 static __device__ unsigned g_wide_cut_count[kWMaxGrid];
 
-// Which XCD a workgroup of a one-dimensional grid runs on, for the host to check that workgroups 8
-// apart share one (the parts of a cut tile synchronise through that XCD's L2 alone).
-static __device__ unsigned g_wide_xcc[kWMaxGrid];
-__global__ __launch_bounds__(512, 1) void wide_xcc_probe_kernel() {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    if (threadIdx.x == 0) {
-        unsigned xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        g_wide_xcc[blockIdx.x] = (xcc & 0xf) + 1;
-        lds[0] = (unsigned char)xcc;   // the LDS allocation is what places one workgroup per CU, as in the real launch
-    }
-}
-
 // Parts a left-over tile is cut into along k: at most as many as there are workgroups per left-over
 // tile, each a whole number of 64-wide stages and at least 8 k-tiles long.  A part costs its share of
 // the tile; every part more costs the last one about an eighth of a tile (it reads that part's 256 KiB of
@@ -516,11 +509,11 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
     // as few as that many tiles allow.  With W workgroups on the XCD and T tiles, workgroup j takes
     // tiles j, j + W, ... of the first W floor(T / W); the R = T mod W tiles left over would keep R
     // workgroups busy for a whole tile while the others wait, so where R <= W / 2 each of them is cut
-    // along k into p = floor(W / R) parts (wide_cut_parts), one per workgroup.  The p - 1 workgroups
+    // along k into up to floor(W / R) parts (wide_cut_parts), one per workgroup.  The workgroups
     // with the lower parts take them first, write their accumulators to their slot of `cut_ws` and
     // count themselves in; the one with the last part - the highest numbered, so the ones it waits
-    // for were dispatched before it - takes it after its whole tiles, starts its accumulators from
-    // the sum of those slots and runs the epilogue.
+    // for were dispatched before it - takes it after its whole tiles and adds those slots to its
+    // accumulators as it runs the epilogue.
     //
     // Copy sources of this wave in a tile: weight tiles 2 wid, 2 wid + 1 of the block; x m-tiles
     // likewise.  Every copy is addressed as a wave-uniform 64-bit base (scalar registers) plus a
@@ -749,12 +742,12 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int t = 0; t < kPMT; ++t)
-                    *reinterpret_cast<f32x4_t*>(mine + (i * 8 + t) * 1024 + wlane) = acc[i][t];
-            // The parts of a tile run on one XCD (the host has checked that workgroups 8 apart do) and so
-            // meet in one L2: a store is counted off vmcnt once it is there, the counter lives there,
-            // and the reader has never touched these lines, so nothing needs writing back or
-            // invalidating - a device-wide release here writes back the whole L2 and the matching
-            // acquire empties it for every workgroup of the XCD (measured: 227 -> 305 us).
+                    asm volatile("global_store_dwordx4 %0, %1, %2 sc1" : : "v"(wlane), "v"(acc[i][t]), "s"(mine + (i * 8 + t) * 1024) : "memory");
+            // Hand-off without fences: sc1 (write-through) stores, each writing whole 128-byte lines;
+            // every wave waits for its own; behind the barrier one lane counts the workgroup in with a
+            // device-scope atomic; the reader polls the counter with an sc1 load, passes a barrier and
+            // reads the sums with sc1 loads only.  A device-wide release / acquire pair here
+            // (__threadfence) writes back the XCD's whole L2 and empties every L1: measured 227 -> 305 us.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0)
@@ -916,29 +909,6 @@ static bool wide_cut_enabled() {
         return !(e && *e) || atoi(e) != 0;
     }();
     return (g_debug_cut >= 0 ? g_debug_cut != 0 : on) && wide_persistent();
-}
-// True once a probe launch on this device has shown that workgroups b and b + 8 k of a grid of one
-// workgroup per CU run on the same XCD.  Probed on the first call with a stream that is not being
-// captured (the probe synchronises that stream); until then, and if the check fails, no tile is cut.
-static bool wide_same_xcd(hipStream_t stream) {
-    static int state[64] = {0};   // 0 unknown, 1 holds, -1 does not
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-    if (state[dev] != 0) return state[dev] > 0;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
-    static LdsOptIn lds_done;
-    const int grid = (int)std::min<long>(kWMaxGrid, wide_grid(kWMaxGrid));
-    static unsigned host[kWMaxGrid];
-    state[dev] = -1;
-    if (ensure_dynamic_lds((const void*)wide_xcc_probe_kernel, kWLds, lds_done) != MV_OK) return false;
-    hipLaunchKernelGGL(wide_xcc_probe_kernel, dim3(grid), dim3(512), kWLds, stream);
-    if (hipStreamSynchronize(stream) != hipSuccess) return false;
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wide_xcc), sizeof(unsigned) * grid) != hipSuccess) return false;
-    for (int b = 0; b < grid; ++b)
-        if (host[b] == 0 || host[b] != host[b & 7]) return false;
-    state[dev] = 1;
-    return true;
 }
 // Does any XCD of an unsliced wide-form launch cut its left-over tiles?  (Then the launch needs one
 // accumulator slot per workgroup.)
@@ -1110,8 +1080,7 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
         // left-over tiles are cut along k inside the launch when the caller's workspace holds a slot per
         // workgroup; without it they are taken whole (slower, same result class)
         if (a.ksplit == 1 && wgrid <= kWMaxGrid && wide_cuts(a.mblocks, a.nblocks, a.kt) && workspace &&
-            aligned16(workspace) && workspace_bytes >= (size_t)wgrid * kWSlotBytes &&
-            wide_same_xcd((hipStream_t)stream))
+            aligned16(workspace) && workspace_bytes >= (size_t)wgrid * kWSlotBytes)
             a.cut_ws = (float*)workspace;
         if (strips == 12)
             hipLaunchKernelGGL((gemm_prefill_wide_kernel<3, 3>), dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
