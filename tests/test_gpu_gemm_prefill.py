@@ -205,6 +205,52 @@ def test_gemm_prefill_wide_form_cuts_left_over_tiles(mv, m, n, k, mode, strips):
     assert float((ulp_diff(cut, whole) == 0).float().mean()) > 0.98
 
 
+_ONE_WORKGROUP_PER_TILE_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import micro_vllm_amd
+from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+g = torch.Generator().manual_seed(77)
+m, n, k = 2500, 9216, 1024
+x = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16)
+w = (torch.randn(n, k, generator=g) * 0.03).to(torch.bfloat16)
+y = gemm_prefill(x.cuda(), StreamedWeight.from_linear(w.cuda()), torch.empty(m, n, dtype=torch.bfloat16, device="cuda"))
+torch.save(y.cpu(), sys.argv[2])
+"""
+
+
+def test_gemm_prefill_wide_form_one_workgroup_per_tile_gives_the_same_bits(mv, tmp_path):
+    """MVLLM_PREFILL_PERSIST=0 (read once per process: a child process) launches one workgroup per tile
+    where the default has one per CU walk several tiles and cut the left-over ones along k: a tile
+    that is not cut is summed in the same order either way, so the outputs must be the same bits
+    wherever the default did not cut, and within the usual bound where it did."""
+    import os
+    import subprocess
+    import sys
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "per_tile.pt")
+    r = subprocess.run([sys.executable, "-c", _ONE_WORKGROUP_PER_TILE_CHILD, root, out], capture_output=True, text=True,
+                       timeout=280, env=dict(os.environ, MVLLM_PREFILL_PERSIST="0"))
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    per_tile = torch.load(out, weights_only=True)
+    g = torch.Generator().manual_seed(77)
+    m, n, k = 2500, 9216, 1024
+    x = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16)
+    w = (torch.randn(n, k, generator=g) * 0.03).to(torch.bfloat16)
+    assert nv.lib().mv_gemm_prefill_form(m, n, k) in (1, 2, 3), "meant to take the wide form"
+    walked = gemm_prefill(x.to(DEV), StreamedWeight.from_linear(w.to(DEV)),
+                          torch.empty(m, n, dtype=torch.bfloat16, device=DEV)).cpu()
+    same = float((ulp_diff(walked, per_tile) == 0).float().mean())
+    assert same > 0.98, f"only {same:.4f} of the outputs agree bit for bit"
+    err = (walked.float() - per_tile.float()).abs()
+    assert bool((err <= 1e-3 + 2 ** -6 * per_tile.float().abs()).all())
+    want = linear_ref(x, w)
+    assert float((ulp_diff(walked, want) == 0).float().mean()) > 0.98
+
+
 def test_gemm_prefill_agrees_with_single_token_kernel(mv):
     """Same weights, same rows: the two kernels differ only in fp32 summation order."""
     from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill, wgemm
