@@ -205,6 +205,43 @@ def test_gemm_prefill_wide_form_cuts_left_over_tiles(mv, m, n, k, mode, strips):
     assert float((ulp_diff(cut, whole) == 0).float().mean()) > 0.98
 
 
+def test_gemm_prefill_cut_tiles_replayed_from_a_captured_graph(mv):
+    """The cut of left-over tiles keeps its counters inside the library and returns them to zero in
+    the launch itself: a captured launch replays any number of times with the bits of the eager one."""
+    import ctypes
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    if _cus() != 256:
+        pytest.skip("the case is laid out for 32 CUs per XCD")
+    L = nv.lib()
+    m, n, k = 3072, 6144, 1024
+    x, w, _ = _mk(m, n, k, seed=11, scale=0.03)
+    xd, sw = x.to(DEV), StreamedWeight.from_linear(w.to(DEV))
+    try:
+        L.mv_debug_prefill_options(1, 12)
+        need = L.mv_gemm_prefill_workspace_bytes(m, n, k)
+        assert need == 256 * 256 * 1024, "meant to cut its left-over tiles"
+        ws = torch.empty(need // 4, dtype=torch.float32, device=DEV)
+        eager = gemm_prefill(xd, sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV), workspace=ws).clone()
+        out = torch.zeros(m, n, dtype=torch.bfloat16, device=DEV)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            side.synchronize()
+            nv.check("begin", L.mv_graph_begin_capture(side.cuda_stream))
+            gemm_prefill(xd, sw, out, workspace=ws)
+            h = ctypes.c_void_p()
+            nv.check("end", L.mv_graph_end_capture(side.cuda_stream, ctypes.byref(h)))
+            for replay in range(3):
+                out.zero_()
+                nv.check("launch", L.mv_graph_launch(h, side.cuda_stream))
+                side.synchronize()
+                assert torch.equal(out, eager), f"replay {replay} differs from the eager launch"
+            L.mv_graph_destroy(h)
+    finally:
+        L.mv_debug_prefill_options(-1, -1)
+
+
 _ONE_WORKGROUP_PER_TILE_CHILD = r"""
 import sys, torch
 sys.path.insert(0, sys.argv[1])
