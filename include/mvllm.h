@@ -203,9 +203,12 @@ int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void*
  * more 256-wide tiles than CUs and the last round of tiles would leave half the CUs or more idle,
  * the tiles of that round are cut along k between the workgroups of the one launch: the lower parts
  * leave their accumulators in the workspace (256 KiB per workgroup) and the workgroup with the last
- * part adds them, in part order, as it applies the epilogue.  That path keeps per-device counters
- * inside the library, so two launches that take it must not overlap on one GPU.  Without the
- * workspace (or with too small a one) the call behaves like mv_gemm_prefill. */
+ * part adds them, in part order, as it applies the epilogue.  The workspace starts with 4 KiB of
+ * counters through which those parts count themselves in: zero-fill the workspace ONCE, when it is
+ * allocated; every launch returns its counters to zero and writes its data behind them, so the
+ * same workspace serves any later call of any shape that fits - one workspace per stream that
+ * issues such calls.  Without the workspace (or with too small a one) the call behaves like
+ * mv_gemm_prefill. */
 size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k);
 int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const void* bias,
                        const void* residual, int64_t ld_res, void* y, int64_t ldy, int m, int n,

@@ -61,8 +61,10 @@ struct PGemmArgs {
     int ksplit, ktps;
     float* partial;
     // wide form: slots of kWSlotBytes, one per workgroup, for the accumulators of a tile that several
-    // workgroups cut along k between them (null: tiles are never cut inside the launch)
+    // workgroups cut along k between them (null: tiles are never cut inside the launch), and the
+    // counters through which the parts of such a tile count themselves in (zero between launches)
     float* cut_ws;
+    unsigned* cut_count;
 };
 
 #ifdef MV_GEMM_STAMP
@@ -462,8 +464,11 @@ constexpr int kWM = 256, kWN = 256;
 constexpr int kWXSlot = 32768, kWWSlot = 16384;
 constexpr int kWLds = 3 * kWXSlot + 4 * kWWSlot;
 constexpr int kWMaxGrid = 1024;
-// one counter per XCD and left-over tile; zero between launches (the last part resets it)
-static __device__ unsigned g_wide_cut_count[kWMaxGrid];
+// The first kWCountBytes of a caller's workspace: one counter per XCD and left-over tile.  The caller
+// zero-fills them once, when it allocates the workspace; the last part of a tile returns its counter
+// to zero, and everything else the library keeps in a workspace (k-slices, accumulator slots) lies
+// behind them.
+constexpr size_t kWCountBytes = kWMaxGrid * sizeof(unsigned);
 
 // Parts a left-over tile is cut into along k: at most as many as there are workgroups per left-over
 // tile, each a whole number of 64-wide stages and at least 8 k-tiles long.  A part costs its share of
@@ -751,7 +756,7 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0)
-                __hip_atomic_fetch_add(&g_wide_cut_count[xcd * wgs + cur.rest], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_fetch_add(&a.cut_count[xcd * wgs + cur.rest], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             // The last part of a cut tile adds the lower parts as it runs the epilogue.  Their
             // workgroups took them first and were dispatched before this one, so the wait is over
@@ -763,7 +768,7 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
             int nlower = 0;
             if (cur.parts > 1) {
                 if (threadIdx.x == 0) {
-                    unsigned* const count = &g_wide_cut_count[xcd * wgs + cur.rest];
+                    unsigned* const count = &a.cut_count[xcd * wgs + cur.rest];
                     for (int spin = 0; spin < (1 << 22) &&
                                        __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(cur.parts - 1);
                          ++spin)
@@ -984,11 +989,11 @@ extern "C" size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k) {
     using namespace mv;
     if (m <= 0 || n <= 0 || k <= 0 || (n % 16) != 0 || (k % 64) != 0) return 0;
     const PrefillPlan plan = prefill_plan(m, n, k / 32);
-    if (plan.ks > 1) return (size_t)plan.ks * m * n * sizeof(float);
+    if (plan.ks > 1) return kWCountBytes + (size_t)plan.ks * m * n * sizeof(float);
     if (!plan.wide) return 0;
     const int mblocks = (m + kWM - 1) / kWM, nblocks = (n / 16 + plan.strips - 1) / plan.strips;
     if (!wide_cuts(mblocks, nblocks, k / 32)) return 0;
-    return (size_t)wide_grid(8L * ((nblocks + 7) / 8) * mblocks) * kWSlotBytes;
+    return kWCountBytes + (size_t)wide_grid(8L * ((nblocks + 7) / 8) * mblocks) * kWSlotBytes;
 }
 
 extern "C" int mv_gemm_prefill_form(int m, int n, int k) {
@@ -1045,11 +1050,16 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
     a.ksplit = plan.ks;
     a.partial = nullptr;
     a.cut_ws = nullptr;
+    a.cut_count = nullptr;
+    // the workspace: kWCountBytes of counters, then the data
+    void* const data = workspace && workspace_bytes > kWCountBytes && aligned16(workspace)
+                           ? (void*)((char*)workspace + kWCountBytes) : nullptr;
+    const size_t data_bytes = data ? workspace_bytes - kWCountBytes : 0;
     bool wide = plan.wide;
     if (a.ksplit > 1) {
         const size_t need = (size_t)a.ksplit * m * n * sizeof(float);
-        if (workspace && workspace_bytes >= need && aligned16(workspace)) {
-            a.partial = (float*)workspace;
+        if (data && data_bytes >= need) {
+            a.partial = (float*)data;
         } else {
             a.ksplit = 1;  // no room for the slices: whole k per tile (slower, same result class)
             wide = false;
@@ -1079,9 +1089,11 @@ extern "C" int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tile
         const long wgrid = wide_grid(ids);
         // left-over tiles are cut along k inside the launch when the caller's workspace holds a slot per
         // workgroup; without it they are taken whole (slower, same result class)
-        if (a.ksplit == 1 && wgrid <= kWMaxGrid && wide_cuts(a.mblocks, a.nblocks, a.kt) && workspace &&
-            aligned16(workspace) && workspace_bytes >= (size_t)wgrid * kWSlotBytes)
-            a.cut_ws = (float*)workspace;
+        if (a.ksplit == 1 && wgrid <= kWMaxGrid && wide_cuts(a.mblocks, a.nblocks, a.kt) && data &&
+            data_bytes >= (size_t)wgrid * kWSlotBytes) {
+            a.cut_ws = (float*)data;
+            a.cut_count = (unsigned*)workspace;
+        }
         if (strips == 12)
             hipLaunchKernelGGL((gemm_prefill_wide_kernel<3, 3>), dim3((unsigned)wgrid), dim3(512), kWLds, (hipStream_t)stream, a);
         else if (strips == 14)

@@ -173,7 +173,8 @@ def gemm_prefill(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
     """Same contract as `wgemm` for any number of rows, on the matrix cores (the prefill
     runner's torch.matmul calls, core/layer/model_prefill.py:42,54,58,62).  `workspace`: fp32
     buffer for k-slices (callers that are stream-captured pass their own fixed one; otherwise the
-    grow-only per-device buffer is used)."""
+    grow-only buffer of the device and stream is used; a caller's own must have been zero-filled when it
+    was allocated and be used for nothing else)."""
     assert x.is_cuda and out.is_cuda and x.dtype == torch.bfloat16
     assert x.dim() == 2 and out.dim() == 2 and x.stride(1) == 1 and out.stride(1) == 1
     m, k = x.shape
@@ -195,8 +196,12 @@ def gemm_prefill(x: torch.Tensor, w: StreamedWeight, out: torch.Tensor,
     ldx = x.stride(0) if m > 1 else max(k, x.stride(0))
     ldy = out.stride(0) if m > 1 else max(ncols, out.stride(0))
     L = nv.lib()
-    need = L.mv_gemm_prefill_workspace_bytes(m, w.n, k)   # k-slices for short prompts, else 0
-    ws = workspace if workspace is not None and workspace.numel() * 4 >= need else gemm_workspace(x.device, need)
+    # k-slices for short prompts, accumulator slots for cut tiles, else 0.  The buffer starts with counters
+    # that stay zero between launches, so it is one of its own (zero-filled when allocated), not the
+    # single-token projections' slab buffer.
+    need = L.mv_gemm_prefill_workspace_bytes(m, w.n, k)
+    ws = (workspace if workspace is not None and workspace.numel() * 4 >= need
+          else nv.stream_workspace("gemm_prefill", x.device, need))
     nv.check("mv_gemm_prefill_ws", L.mv_gemm_prefill_ws(
         x.data_ptr(), ldx, w.tiles.data_ptr(), nv.ptr(bias), nv.ptr(residual), ld_res,
         out.data_ptr(), ldy, m, w.n, k, flags, ws.data_ptr() if ws is not None else None,

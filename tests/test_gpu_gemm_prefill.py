@@ -101,7 +101,7 @@ def test_gemm_prefill_wide_form(mv, m, n, k, mode):
     if _cus() == 256:
         assert form == WIDE_FORM.get((m, n), 1), f"tile width of {(m, n, k)}: form {form}"
     if k >= 8192:
-        assert nv.lib().mv_gemm_prefill_workspace_bytes(m, n, k) == 2 * m * n * 4, "meant to be cut in two k-slices"
+        assert nv.lib().mv_gemm_prefill_workspace_bytes(m, n, k) == 4096 + 2 * m * n * 4, "meant to be cut in two k-slices"
     x, w, g = _mk(m, n, k, seed=m + n + k, scale=0.03)
     bias = torch.randn(n, generator=g).to(torch.bfloat16) if mode == "bias" else None
     res = torch.randn(m, n, generator=g).to(torch.bfloat16) if mode == "residual" else None
@@ -174,7 +174,7 @@ def test_gemm_prefill_wide_form_cuts_left_over_tiles(mv, m, n, k, mode, strips):
 
     try:
         L.mv_debug_prefill_options(1, strips)
-        assert L.mv_gemm_prefill_workspace_bytes(m, n, k) == 256 * 256 * 1024, "meant to cut its left-over tiles"
+        assert L.mv_gemm_prefill_workspace_bytes(m, n, k) == 4096 + 256 * 256 * 1024, "meant to cut its left-over tiles"
         cut, again = run(), run()
         L.mv_debug_prefill_options(0, strips)
         assert L.mv_gemm_prefill_workspace_bytes(m, n, k) == 0
@@ -221,8 +221,8 @@ def test_gemm_prefill_cut_tiles_replayed_from_a_captured_graph(mv):
     try:
         L.mv_debug_prefill_options(1, 12)
         need = L.mv_gemm_prefill_workspace_bytes(m, n, k)
-        assert need == 256 * 256 * 1024, "meant to cut its left-over tiles"
-        ws = torch.empty(need // 4, dtype=torch.float32, device=DEV)
+        assert need == 4096 + 256 * 256 * 1024, "meant to cut its left-over tiles"
+        ws = torch.zeros(need // 4, dtype=torch.float32, device=DEV)   # starts with the parts' counters
         eager = gemm_prefill(xd, sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV), workspace=ws).clone()
         out = torch.zeros(m, n, dtype=torch.bfloat16, device=DEV)
         side = torch.cuda.Stream()
@@ -240,6 +240,37 @@ def test_gemm_prefill_cut_tiles_replayed_from_a_captured_graph(mv):
             L.mv_graph_destroy(h)
     finally:
         L.mv_debug_prefill_options(-1, -1)
+
+
+def test_gemm_prefill_cut_tiles_on_two_streams_at_once(mv):
+    """Two streams issue launches that cut their left-over tiles, back to back and unsynchronised: each
+    stream has its own workspace (counters and accumulator slots), so neither sees the other's parts."""
+    from micro_vllm_amd import _native as nv
+    from micro_vllm_amd.kernel.linear import StreamedWeight, gemm_prefill
+
+    if _cus() != 256:
+        pytest.skip("the case is laid out for 32 CUs per XCD")
+    L = nv.lib()
+    m, n, k = 3072, 6144, 1024
+    cases = []
+    for seed in (21, 22):
+        x, w, _ = _mk(m, n, k, seed=seed, scale=0.03)
+        cases.append((x.to(DEV), StreamedWeight.from_linear(w.to(DEV))))
+    try:
+        L.mv_debug_prefill_options(1, 12)
+        serial = [gemm_prefill(xd, sw, torch.empty(m, n, dtype=torch.bfloat16, device=DEV)).clone() for xd, sw in cases]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [torch.zeros(m, n, dtype=torch.bfloat16, device=DEV) for _ in cases]
+        for _ in range(4):
+            for st, (xd, sw), out in zip(streams, cases, outs):
+                with torch.cuda.stream(st):
+                    gemm_prefill(xd, sw, out)
+        torch.cuda.synchronize()
+    finally:
+        L.mv_debug_prefill_options(-1, -1)
+    for i, (out, want) in enumerate(zip(outs, serial)):
+        assert torch.equal(out, want), f"stream {i}: differs from the launch on its own"
 
 
 _ONE_WORKGROUP_PER_TILE_CHILD = r"""
