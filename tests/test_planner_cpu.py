@@ -59,6 +59,16 @@ def test_prefill_forms(mv):
     assert L.mv_gemm_prefill_form(128, 4096, 4096) == 0 and L.mv_gemm_prefill_workspace_bytes(128, 4096, 4096) > 0
     assert L.mv_gemm_prefill_form(4096, 4096, 192) == 0        # fewer than 8 k-tiles
     assert L.mv_gemm_prefill_form(4096, 4100, 4096) == 0       # not a shape the kernels take at all
+    # left-over tiles cut along k inside the launch (a slot of 256 KiB per workgroup behind 4 KiB of counters)
+    # where that beats a wider or narrower tile in whole rounds; nothing to cut where the rounds are whole
+    cut = 4096 + 256 * 256 * 1024
+    assert L.mv_gemm_prefill_form(3072, 6144, 4096) == 2 and L.mv_gemm_prefill_workspace_bytes(3072, 6144, 4096) == cut
+    assert L.mv_gemm_prefill_workspace_bytes(4096, 6144, 4096) == 0      # 64 tiles of 192 columns per XCD: two rounds
+    assert L.mv_gemm_prefill_workspace_bytes(4096, 28672, 4096) == 0     # seven rounds
+    assert L.mv_gemm_prefill_workspace_bytes(2048, 28672, 4096) == 0     # four rounds of 224 columns, not 3.5 cut
+    assert L.mv_gemm_prefill_form(3072, 28672, 4096) == 3 and L.mv_gemm_prefill_workspace_bytes(3072, 28672, 4096) == 0
+    # two k-slices and a reduction launch where the tiles fill three eighths to half of the CUs and k is long
+    assert L.mv_gemm_prefill_workspace_bytes(2048, 4096, 14336) == 4096 + 2 * 2048 * 4096 * 4
     # attention: 256-row workgroups for long chunks that fill their rounds
     assert L.mv_paged_attn_prefill_form(1, 4096, 32, 8) == 8
     assert L.mv_paged_attn_prefill_form(1, 3072, 32, 8) == 8
