@@ -17,10 +17,10 @@ for m in ([int(a) for a in sys.argv[1:]] or [32]):
         x = torch.randn(m, k, device=dev).to(torch.bfloat16)
         y = torch.empty(m, n // 2 if sw else n, dtype=torch.bfloat16, device=dev)
         res = []
-        for sg in (1, 2, 4):
+        for sg in (1, 2, 3, 4, 7):
             if L.mv_wgemm_tune(3, sg) != 0:
                 continue
-            for ks in (1, 2, 4):
+            for ks in (1, 2, 3, 4, 8):
                 L.mv_wgemm_tune(1, ks)
                 for bpc in (1, 2):
                     L.mv_wgemm_tune(0, bpc)
