@@ -207,7 +207,9 @@ int mv_gemm_prefill(const void* x, int64_t ldx, const void* w_tiles, const void*
  * counters through which those parts count themselves in: zero-fill the workspace ONCE, when it is
  * allocated; every launch returns its counters to zero and writes its data behind them, so the
  * same workspace serves any later call of any shape that fits - one workspace per stream that
- * issues such calls.  Without the workspace (or with too small a one) the call behaves like
+ * issues such calls.  (A part that has not arrived after about 20 s - a workgroup of the launch
+ * lost - ends the launch with a trap, i.e. the process, rather than returning sums that lack a
+ * part of k.)  Without the workspace (or with too small a one) the call behaves like
  * mv_gemm_prefill. */
 size_t mv_gemm_prefill_workspace_bytes(int m, int n, int k);
 int mv_gemm_prefill_ws(const void* x, int64_t ldx, const void* w_tiles, const void* bias,

@@ -768,11 +768,14 @@ __device__ __forceinline__ void wide_tile(const PGemmArgs& a, unsigned char* lds
             int nlower = 0;
             if (cur.parts > 1) {
                 if (threadIdx.x == 0) {
+                    // bounded (about 20 s of 0.6-us naps): parts that never arrive mean a lost workgroup,
+                    // and a trap that ends the process beats sums that silently lack a part of k
                     unsigned* const count = &a.cut_count[xcd * wgs + cur.rest];
-                    for (int spin = 0; spin < (1 << 22) &&
-                                       __hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(cur.parts - 1);
-                         ++spin)
+                    int spin = 0;
+                    while (__hip_atomic_load(count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(cur.parts - 1)) {
+                        if (++spin > (1 << 25)) __builtin_trap();
                         __builtin_amdgcn_s_sleep(16);
+                    }
                     __hip_atomic_store(count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
